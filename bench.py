@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X-native MRI ray-marcher.
+
+Metric (BASELINE.json): Msamples/s and achieved HBM GB/s, 512^3 fp32 volume @ 1024^2 x 512
+steps.  The N=1 workload is BASELINE config 3 ("C3"): one fp32 channel, perspective rays,
+central-difference gradient + Blinn-Phong shading, early-ray termination (T <= 0.01), on the
+synthetic scene of SURVEY.md section 8(d) (``mrirt.synth``; intensityAlpha 16 so that
+termination fires).  A *step* is one rendered frame: ray generation, march, composite and the
+framebuffer store — and, for N > 1, the RCCL gather of the tiles to rank 0 plus de-tiling.
+
+``value`` = live samples of all ranks' frames / wall time.  Live samples (march-loop iterations
+that fetch the volume) are counted by the kernel itself in an untimed pass, so skipping work
+cannot inflate the rate.  Inputs are resident in HBM before the timed region.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling — the image grows to
+about N x 1024^2 pixels (side 1024*sqrt(N) rounded to the tile size), 64x64 tiles dealt
+round-robin to ranks, volume replicated, one gather per frame.
+
+Prints ONE JSON line (rank 0).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0         # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+BYTES_PER_SAMPLE = 32         # 8 taps x 4 B, one fp32 channel          
+BYTES_PER_SHADED = 192        # + 6 x 8 taps x 4 B central differences  
+BYTES_PER_PIXEL = 16          # fp32 RGBA framebuffer store
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--volume", type=int, default=512, help="volume side N (N^3 fp32)")
+    ap.add_argument("--image", type=int, default=0, help="image side; 0 = 1024*sqrt(gpus) rounded to the tile")
+    ap.add_argument("--march-steps", type=int, default=512)
+    ap.add_argument("--math", default="strict", choices=["strict", "fast"])
+    ap.add_argument("--layout", default="brick", choices=["brick", "linear"])
+    ap.add_argument("--no-shade", action="store_true", help="reference-only K1 (no gradient shading)")
+    ap.add_argument("--alpha", type=float, default=16.0, help="intensityAlpha (16 = dense preset: ERT fires)")
+    ap.add_argument("--variant", type=int, default=0, help="kernelVariant (experiments)")
+    ap.add_argument("--tile", type=int, default=64)
+    ap.add_argument("--cpu-rows", type=int, default=-1, help="rows of the frame the CPU baseline renders; 0 = skip, -1 = auto")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(params, vol, ext, rows, n_image):
+    """The C/OpenMP oracle (oracle/oracle_c.c) timed on the host cores, on a band of rows of the
+    same frame.  A reported baseline, not the target."""
+    from oracle import oracle_c
+    oracle_c.lib()
+    r0 = max(0, n_image // 2 - rows // 2)
+    r1 = min(n_image, r0 + rows)
+    okeys = ("cameraMode", "orthoHalfHeight", "shadeMode", "ka", "kd", "ks", "specPow2", "gradEps")
+    oext = {k: v for k, v in ext.items() if k in okeys}
+    t = time.perf_counter()
+    _, aux = oracle_c.brats_main(params, [vol], None, None, oext, return_aux=True, rows=(r0, r1))
+    dt = time.perf_counter() - t
+    cores = int(os.environ.get("OMP_NUM_THREADS", 0)) or (os.cpu_count() or 1)
+    return {"value": round(aux["live_samples"] / dt / 1e6, 3), "unit": "Msamples/s", "cores": cores,
+            "kind": "port",
+            "sample": f"rows {r0}..{r1 - 1} of the same {n_image}x{n_image} frame "
+                      f"({aux['live_samples']} live samples, {dt:.1f} s, C/OpenMP oracle, all host threads)"}
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    import mrirt
+    from mrirt import synth, tiles
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the ray-marcher has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    n = a.volume
+    image = a.image or int(round(1024 * math.sqrt(world) / a.tile)) * a.tile
+    vol = synth.synth_volume(n)                                   # host, deterministic
+    params = synth.brats_scene(n, image, a.march_steps, channels=1, intensity_alpha=a.alpha)
+    ext = {} if a.no_shade else dict(synth.SHADE_EXT)
+    ext.update(math=a.math, layout=a.layout, kernelVariant=a.variant)
+    grid = mrirt.upload_grid(vol, (n, n, n), a.layout)            # resident in HBM (bricked on device)
+    torch.cuda.synchronize()
+
+    if world > 1:
+        my_ext = tiles.shard_ext(ext, rank, world, a.tile)
+        n_local = tiles.local_tile_count(image, image, a.tile, rank, world)
+        local = torch.empty((n_local, a.tile, a.tile, 4), dtype=torch.float32, device=dev)
+    else:
+        my_ext = ext
+        local = torch.empty((image, image, 4), dtype=torch.float32, device=dev)
+
+    def frame():
+        mrirt.render_brats(params, [grid], out=local, ext=my_ext)
+        if world > 1:
+            return tiles.gather_frame(local, image, image, a.tile)
+        return local
+
+    # untimed: sample accounting by the kernel's own counters
+    _, st = mrirt.render_brats(params, [grid], out=local, ext=my_ext, stats=True)
+    counts = torch.tensor([st["live_samples"], st["shaded_samples"]], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(counts)
+    live, shaded = int(counts[0]), int(counts[1])
+
+    for _ in range(a.warmup):
+        frame()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    t0 = time.perf_counter()
+    for s in range(a.steps):
+        # HIP events on the launch stream bracket the march kernel alone (roofline);
+        # the wall clock brackets the whole step (value)
+        ev[s][0].record()
+        mrirt.render_brats(params, [grid], out=local, ext=my_ext)
+        ev[s][1].record()
+        if world > 1:
+            tiles.gather_frame(local, image, image, a.tile)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        e = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(e, op=dist.ReduceOp.MAX)
+        elapsed = float(e[0])
+    kernel_ms = float(np.mean([s.elapsed_time(t) for s, t in ev]))
+
+    if rank == 0:
+        value = live * a.steps / elapsed / 1e6
+        # roofline of the dominant kernel (brats_march_kernel) on THIS rank's launch
+        my_live, my_shaded = st["live_samples"], st["shaded_samples"]
+        px = local.numel() // 4
+        alg_bytes = my_live * BYTES_PER_SAMPLE + my_shaded * BYTES_PER_SHADED + px * BYTES_PER_PIXEL
+        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "live Msamples/s, 512^3 fp32 volume @ 1024^2 x 512 steps (gradient shading + ERT)",
+            "value": round(value, 1), "unit": "Msamples/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(elapsed / a.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": ("C3" if not a.no_shade else "K1-reference") +
+                       f": {n}^3 fp32 volume, {image}x{image} px, {a.march_steps} steps/ray, perspective, "
+                       + ("central-difference gradient + Blinn-Phong + " if not a.no_shade else "") + "ERT",
+                       "math": a.math, "layout": a.layout, "intensityAlpha": a.alpha,
+                       "tiles": f"{a.tile}x{a.tile} round-robin over {world} rank(s)",
+                       "live_samples_per_frame": live, "shaded_samples_per_frame": shaded,
+                       "nominal_samples_per_frame": image * image * a.march_steps,
+                       "kernel_variant": a.variant},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": "brats_march_kernel", "kernel_ms": round(kernel_ms, 4),
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "bytes_per_sample": BYTES_PER_SAMPLE + (0 if a.no_shade else BYTES_PER_SHADED)},
+        }
+        if not a.no_cpu_baseline and a.cpu_rows != 0 and world == 1:
+            rows = a.cpu_rows if a.cpu_rows > 0 else (192 if not a.no_shade else 512)
+            out["cpu_baseline"] = cpu_baseline(params, vol, ext, min(rows, image), image)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

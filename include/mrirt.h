@@ -1,0 +1,215 @@
+/* mrirt.h — C ABI of the MI355X-native MRI volume ray-marcher (libmrirt.so).
+ *
+ * This is the drop-in boundary for the reference's render call.  The reference
+ * (klukaszek/MRI-RayTracer) has no FFI of its own: its render call is the third-party slangpy
+ *     kernel.dispatch(thread_count=[W,H,1], vars={...}, command_encoder=ce)
+ * at inr/viewer/brats_viewer.py:431-442, scripts/volumeRendering/app.py:350-358 and
+ * scripts/raymarch/app.py:212-223, binding buffers BY NAME to the Slang globals.  Each entry
+ * point below replaces one of those dispatches: same inputs (the Slang cbuffer as a POD, the
+ * StructuredBuffers as plain device pointers), same output (one RGBA pixel per thread).
+ *
+ * Rules of the boundary:
+ *   - extern "C", plain pointers and sizes, no torch / C++ types;
+ *   - every data pointer is a DEVICE pointer owned by the caller; nothing is retained;
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*) and NOT synchronised;
+ *   - returns MRIRT_OK (0) or a negative MrirtStatus; never throws across the boundary;
+ *   - parameter structs are read on the host during the call (they may live on the stack).
+ */
+#ifndef MRIRT_H
+#define MRIRT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MRIRT_ABI_VERSION 1
+
+typedef enum MrirtStatus {
+    MRIRT_OK = 0,
+    MRIRT_ERR_NULL = -1,       /* a required pointer is NULL                         */
+    MRIRT_ERR_DIMS = -2,       /* volume dims < 2 on an axis, or image size 0        */
+    MRIRT_ERR_LAYOUT = -3,     /* unknown layout / dtype / mode                      */
+    MRIRT_ERR_LAUNCH = -4,     /* hipLaunch / HIP runtime error (see mrirt_last_hip_error) */
+    MRIRT_ERR_ARG = -5,        /* inconsistent argument (pitch < width, bad tile spec, ...) */
+    MRIRT_ERR_NO_DEVICE = -6   /* no gfx950 device visible                           */
+} MrirtStatus;
+
+/* ------------------------------------------------------------------------------------ */
+/* K1  brats_main                                                                        */
+/* ------------------------------------------------------------------------------------ */
+
+/* Field-for-field mirror of `struct Params`, inr/viewer/brats_rt.slang:12-31, including
+ * its hand padding (so the 16-byte cbuffer layout is preserved).                        */
+typedef struct MrirtBratsParams {
+    uint32_t imageSize[2]; float fovY; float pad0;
+    float eye[3]; float pad1;
+    float U[3]; float pad2; float V[3]; float pad3; float W[3]; float pad4;
+    float volMin[3]; float pad5; float voxelSize[3]; float pad6; uint32_t dims[3]; uint32_t pad7;
+    float stepSize; float nearT; float farT; float pad8;
+    float bgColor[3]; float pad9;
+    uint32_t volEnabled[4];
+    float volWeight[4];
+    float ww; float wl; float intensityAlpha; float padInt;
+    float gamma; float gradBoost; float gradScale; float padTone;   /* gradBoost/gradScale: unread, as in the shader */
+    uint32_t showSeg;
+    uint32_t showPred;
+    uint32_t padFlags[2];
+    float lutColorAlpha[8][4];
+} MrirtBratsParams;
+
+/* Grid storage layouts.  LINEAR is the reference's (x fastest: x + y*X + z*X*Y,
+ * inr/viewer/brats_viewer.py:64).  BRICK is this library's HBM layout (DESIGN.md "Data
+ * layout"): 4x4x2-voxel bricks, one 128-byte line per fp32 brick, produced by mrirt_brick_*. */
+typedef enum MrirtLayout { MRIRT_LAYOUT_LINEAR = 0, MRIRT_LAYOUT_BRICK = 1 } MrirtLayout;
+
+typedef enum MrirtMath {
+    MRIRT_MATH_STRICT = 0,  /* unfused fp32 in the oracle's order, fp64-backed exp/pow: bit-faithful */
+    MRIRT_MATH_FAST = 1     /* FMA contraction, hardware exp2/rcp; within the 1e-4 image tolerance   */
+} MrirtMath;
+
+typedef enum MrirtOutFormat { MRIRT_OUT_RGBA32F = 0, MRIRT_OUT_RGBA16F = 1 /* reference's rgba16_float */ } MrirtOutFormat;
+
+/* Build-defined extensions (no reference counterpart).  A NULL pointer
+ * or an all-zero struct selects exactly the reference's behaviour.                         */
+typedef struct MrirtRenderExt {
+    uint32_t cameraMode;        /* 0 perspective (brats_rt.slang:36-46), 1 orthographic        */
+    float    orthoHalfHeight;
+    uint32_t shadeMode;         /* 0 off, 1 lattice central-difference gradient + Blinn-Phong  */
+    float    ka, kd, ks;
+    uint32_t specPow2;          /* specular exponent 2^specPow2 by repeated squaring           */
+    float    gradEps;
+    uint32_t ertOverride;       /* 0: the reference's T > 0.01; 1: use ertThreshold            */
+    float    ertThreshold;
+    uint32_t math;              /* MrirtMath                                                   */
+    uint32_t outFormat;         /* MrirtOutFormat                                              */
+    uint32_t layout;            /* MrirtLayout of ALL bound fp32 grids and label grids         */
+    /* Image-tile sharding (one process per GPU).  tileWorld <= 1: whole image into
+     * out[y*pitch + x].  Otherwise this call renders the tiles t with t % tileWorld ==
+     * tileRank (t = ty*tilesX + tx, tiles of tileSize^2 pixels) into a COMPACT buffer
+     * out[local_tile][tileSize][tileSize][4]; pitch is ignored.                            */
+    uint32_t tileSize, tileRank, tileWorld;
+    uint32_t kernelVariant;     /* 0 = library default; others select experimental kernels (bench/tests) */
+    uint32_t reserved[3];
+} MrirtRenderExt;
+
+/* Drop-in for kernel.dispatch(...) of brats_main, inr/viewer/brats_viewer.py:431-442.
+ *   vol[m]  = gIntensity<m>  (fp32, X*Y*Z, LINEAR; may be NULL when volEnabled[m] == 0)
+ *   labels  = gLabels, preds = gPreds (uint32 per voxel; may be NULL when showSeg/showPred == 0)
+ *   out_rgba= gOutput as fp32 RGBA, pitch_px pixels per row (>= imageSize[0])             */
+int mrirt_render_brats(const MrirtBratsParams* params, const float* const vol[4],
+                       const uint32_t* labels, const uint32_t* preds,
+                       float* out_rgba, int64_t pitch_px, void* stream);
+
+/* As above with extensions; grids are in ext->layout, out in ext->outFormat.
+ * stats_dev (optional): 2 device uint64 counters, atomically incremented by
+ * {live samples, gradient-shaded samples} — used for sample accounting, not timed.       */
+int mrirt_render_brats_ex(const MrirtBratsParams* params, const MrirtRenderExt* ext,
+                          const void* const vol[4], const void* labels, const void* preds,
+                          void* out_rgba, int64_t pitch_px, uint64_t* stats_dev, void* stream);
+
+/* Host CPU twin? No: the product has no CPU fallback.  The CPU restatement lives in oracle/. */
+
+/* ------------------------------------------------------------------------------------ */
+/* Brick layout conversion (load-time; replaces create_buffer + copy_from_numpy,         */
+/* inr/viewer/brats_viewer.py:219-230)                                                   */
+/* ------------------------------------------------------------------------------------ */
+
+/* Number of ELEMENTS (not bytes) a bricked grid of `dims` occupies. */
+int64_t mrirt_brick_elems(const uint32_t dims[3]);
+/* linear (x fastest) -> bricked; elem_bytes in {1,4}; dst holds mrirt_brick_elems(dims) elements. */
+int mrirt_brick_grid(const void* linear, void* bricked, const uint32_t dims[3], uint32_t elem_bytes, void* stream);
+/* inverse, for round-trip tests */
+int mrirt_unbrick_grid(const void* bricked, void* linear, const uint32_t dims[3], uint32_t elem_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------ */
+/* K2  volume_cs                                                                         */
+/* ------------------------------------------------------------------------------------ */
+
+/* Mirror of `struct Params`, scripts/volumeRendering/volume_render.slang:9-21. */
+typedef struct MrirtVolumeParams {
+    uint32_t imageSize[2]; float fovY; float stepCount;
+    float nearPlane; float farPlane;
+    float eye[3]; float padEye; float U[3]; float padU; float V[3]; float padV; float W[3]; float padW;
+    uint32_t volDim[3]; uint32_t padDim;
+} MrirtVolumeParams;
+
+typedef enum MrirtVoxelMode {
+    MRIRT_VOX_U32X4 = 0,   /* reference: StructuredBuffer<uint4>, one u32 per u8 voxel (app.py:150-153) */
+    MRIRT_VOX_U8 = 1,      /* real bytes (1 B/voxel)                                                     */
+    MRIRT_VOX_F32 = 2      /* fp32 grid (build-defined generalisation)                    */
+} MrirtVoxelMode;
+
+/* Drop-in for kernel.dispatch(...) of volume_cs, scripts/volumeRendering/app.py:350-358.
+ * volume = gVolumeU8 in `mode`; ext may be NULL (uses cameraMode/orthoHalfHeight/math/outFormat/tiles). */
+int mrirt_render_volume(const MrirtVolumeParams* params, const MrirtRenderExt* ext, const void* volume,
+                        uint32_t mode, void* out_rgba, int64_t pitch_px, uint64_t* stats_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------ */
+/* K3  raymarch_cs                                                                       */
+/* ------------------------------------------------------------------------------------ */
+
+/* Mirror of `struct Params` + the four float3 globals, scripts/raymarch/raymarch.slang:7-21. */
+typedef struct MrirtSdfParams {
+    uint32_t imageSize[2]; float fovY; uint32_t maxSteps;
+    float maxDistance; float hitThreshold; float normalEps; float pad0;
+    float gEye[3]; float pad1; float gU[3]; float pad2; float gV[3]; float pad3; float gW[3]; float pad4;
+} MrirtSdfParams;
+
+/* Drop-in for kernel.dispatch(...) of raymarch_cs, scripts/raymarch/app.py:212-223.
+ * width/height are the render_texture dimensions (the shader queries the texture, :64). */
+int mrirt_render_sdf(const MrirtSdfParams* params, uint32_t width, uint32_t height,
+                     float* out_rgba, int64_t pitch_px, void* stream);
+
+/* ------------------------------------------------------------------------------------ */
+/* Tile sharding helpers (multi-GPU)                               */
+/* ------------------------------------------------------------------------------------ */
+/* number of tiles rank `rank` of `world` renders for a W x H image */
+int64_t mrirt_tiles_for_rank(uint32_t width, uint32_t height, uint32_t tileSize, uint32_t rank, uint32_t world);
+/* scatter gathered compact tile buffers [world][max_local][ts][ts][4] back into a pitch-linear frame */
+int mrirt_detile(const void* gathered, void* frame, uint32_t width, uint32_t height, int64_t pitch_px,
+                 uint32_t tileSize, uint32_t world, uint32_t outFormat, void* stream);
+
+/* ------------------------------------------------------------------------------------ */
+/* INR forward (inr/inr/model.py:11-50,119-141; notebooks/neumors_inr.ipynb:1165-1178)   */
+/* ------------------------------------------------------------------------------------ */
+typedef enum MrirtInrKind { MRIRT_INR_FOURIER_RELU = 0, MRIRT_INR_SIREN = 1 } MrirtInrKind;
+
+typedef struct MrirtInrDesc {
+    uint32_t kind;           /* MrirtInrKind                                                    */
+    uint32_t numLayers;      /* linear layers incl. head (<= 8)                                 */
+    uint32_t inDim;          /* raw input width (3 + 6K + M for Fourier; 7 for the SIREN)       */
+    uint32_t outDim;         /* classes (<= 16)                                                 */
+    uint32_t hidden;         /* hidden width (multiple of 32, <= 256)                           */
+    uint32_t fourierFreqs;   /* K (Fourier kind)                                                */
+    uint32_t numMods;        /* M                                                               */
+    float    w0;             /* SIREN first-layer frequency (30)                                */
+    const void* weights;     /* device: packed bf16 weights, see mrirt_inr_pack_bytes           */
+    const float* biases;     /* device: fp32 biases, layers concatenated, each padded to its padded out width */
+} MrirtInrDesc;
+
+/* bytes of the packed bf16 weight image for a network shape */
+int64_t mrirt_inr_pack_bytes(const MrirtInrDesc* desc);
+/* pack fp32 row-major [in,out] weights (device, layers concatenated unpadded) into the MFMA image */
+int mrirt_inr_pack_weights(const MrirtInrDesc* desc, const float* w_f32, void* packed, void* stream);
+/* logits[n][outDim] (fp32) and/or argmax[n] (int16) for n points.
+ * coords[n][3] in [-1,1]; feats[n][numMods].  Either output may be NULL.                 */
+int mrirt_inr_forward(const MrirtInrDesc* desc, const float* coords, const float* feats, int64_t n,
+                      float* logits, int16_t* argmax, void* stream);
+/* predict_volume (inr/inr/model.py:119-141): mods[M][H][W][D] fp32 -> pred[H][W][D] int16 */
+int mrirt_inr_predict_volume(const MrirtInrDesc* desc, const float* mods, const uint32_t hwd[3],
+                             int16_t* pred, void* stream);
+
+/* ------------------------------------------------------------------------------------ */
+/* Misc                                                                                  */
+/* ------------------------------------------------------------------------------------ */
+int mrirt_abi_version(void);
+const char* mrirt_status_string(int status);
+int mrirt_last_hip_error(void);            /* hipError_t of the last failed HIP call on this thread */
+uint32_t mrirt_sizeof(uint32_t which);     /* 0 BratsParams, 1 RenderExt, 2 VolumeParams, 3 SdfParams, 4 InrDesc */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MRIRT_H */

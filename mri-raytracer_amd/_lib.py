@@ -1,0 +1,178 @@
+"""ctypes binding of libmrirt.so (the C ABI declared in include/mrirt.h).
+
+The HIP library is the product: there is NO CPU fallback.  If the shared object is missing or
+stale, :func:`lib` raises — render calls never silently route anywhere else.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import pathlib
+import subprocess
+from typing import List, Optional
+
+PKG_DIR = pathlib.Path(__file__).resolve().parent
+CSRC = PKG_DIR / "csrc"
+INCLUDE = PKG_DIR.parent / "include"
+SO_PATH = PKG_DIR / "libmrirt.so"
+HIP_SOURCES = ["brats_march.hip", "volume_march.hip", "grid_ops.hip", "inr_mlp.hip"]
+HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17", "-Wall"]
+
+# every extern "C" symbol include/mrirt.h declares
+ABI_SYMBOLS = [
+    "mrirt_render_brats", "mrirt_render_brats_ex", "mrirt_brick_elems", "mrirt_brick_grid",
+    "mrirt_unbrick_grid", "mrirt_render_volume", "mrirt_render_sdf", "mrirt_tiles_for_rank",
+    "mrirt_detile", "mrirt_inr_pack_bytes", "mrirt_inr_pack_weights", "mrirt_inr_forward",
+    "mrirt_inr_predict_volume", "mrirt_abi_version", "mrirt_status_string", "mrirt_last_hip_error",
+    "mrirt_sizeof",
+]
+
+OK = 0
+LAYOUT_LINEAR, LAYOUT_BRICK = 0, 1
+MATH_STRICT, MATH_FAST = 0, 1
+OUT_RGBA32F, OUT_RGBA16F = 0, 1
+VOX_U32X4, VOX_U8, VOX_F32 = 0, 1, 2
+INR_FOURIER_RELU, INR_SIREN = 0, 1
+
+f32, u32 = C.c_float, C.c_uint32
+
+
+class BratsParams(C.Structure):
+    """MrirtBratsParams == struct Params of inr/viewer/brats_rt.slang:12-31."""
+    _fields_ = [
+        ("imageSize", u32 * 2), ("fovY", f32), ("pad0", f32),
+        ("eye", f32 * 3), ("pad1", f32),
+        ("U", f32 * 3), ("pad2", f32), ("V", f32 * 3), ("pad3", f32), ("W", f32 * 3), ("pad4", f32),
+        ("volMin", f32 * 3), ("pad5", f32), ("voxelSize", f32 * 3), ("pad6", f32), ("dims", u32 * 3), ("pad7", u32),
+        ("stepSize", f32), ("nearT", f32), ("farT", f32), ("pad8", f32),
+        ("bgColor", f32 * 3), ("pad9", f32),
+        ("volEnabled", u32 * 4), ("volWeight", f32 * 4),
+        ("ww", f32), ("wl", f32), ("intensityAlpha", f32), ("padInt", f32),
+        ("gamma", f32), ("gradBoost", f32), ("gradScale", f32), ("padTone", f32),
+        ("showSeg", u32), ("showPred", u32), ("padFlags", u32 * 2),
+        ("lutColorAlpha", (f32 * 4) * 8),
+    ]
+
+
+class RenderExt(C.Structure):
+    _fields_ = [
+        ("cameraMode", u32), ("orthoHalfHeight", f32),
+        ("shadeMode", u32), ("ka", f32), ("kd", f32), ("ks", f32), ("specPow2", u32), ("gradEps", f32),
+        ("ertOverride", u32), ("ertThreshold", f32),
+        ("math", u32), ("outFormat", u32), ("layout", u32),
+        ("tileSize", u32), ("tileRank", u32), ("tileWorld", u32),
+        ("kernelVariant", u32), ("reserved", u32 * 3),
+    ]
+
+
+class VolumeParams(C.Structure):
+    """MrirtVolumeParams == struct Params of scripts/volumeRendering/volume_render.slang:9-21."""
+    _fields_ = [
+        ("imageSize", u32 * 2), ("fovY", f32), ("stepCount", f32), ("nearPlane", f32), ("farPlane", f32),
+        ("eye", f32 * 3), ("padEye", f32), ("U", f32 * 3), ("padU", f32), ("V", f32 * 3), ("padV", f32),
+        ("W", f32 * 3), ("padW", f32), ("volDim", u32 * 3), ("padDim", u32),
+    ]
+
+
+class SdfParams(C.Structure):
+    """MrirtSdfParams == struct Params + gEye/gU/gV/gW of scripts/raymarch/raymarch.slang:7-21."""
+    _fields_ = [
+        ("imageSize", u32 * 2), ("fovY", f32), ("maxSteps", u32),
+        ("maxDistance", f32), ("hitThreshold", f32), ("normalEps", f32), ("pad0", f32),
+        ("gEye", f32 * 3), ("pad1", f32), ("gU", f32 * 3), ("pad2", f32), ("gV", f32 * 3), ("pad3", f32),
+        ("gW", f32 * 3), ("pad4", f32),
+    ]
+
+
+class InrDesc(C.Structure):
+    _fields_ = [
+        ("kind", u32), ("numLayers", u32), ("inDim", u32), ("outDim", u32), ("hidden", u32),
+        ("fourierFreqs", u32), ("numMods", u32), ("w0", f32),
+        ("weights", C.c_void_p), ("biases", C.c_void_p),
+    ]
+
+
+class MrirtError(RuntimeError):
+    def __init__(self, status: int, where: str):
+        l = lib()
+        msg = l.mrirt_status_string(status).decode()
+        extra = f" (hipError {l.mrirt_last_hip_error()})" if status == -4 else ""
+        super().__init__(f"{where}: {msg}{extra} [status {status}]")
+        self.status = status
+
+
+def hipcc_command(out: Optional[pathlib.Path] = None, extra: Optional[List[str]] = None) -> List[str]:
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    return [hipcc, *HIPCC_FLAGS, *(extra or []), f"-I{INCLUDE}", *[str(CSRC / s) for s in HIP_SOURCES],
+            "-o", str(out or SO_PATH)]
+
+
+def _stale() -> bool:
+    if not SO_PATH.exists():
+        return True
+    t = SO_PATH.stat().st_mtime
+    srcs = list(CSRC.glob("*.hip")) + list(CSRC.glob("*.h")) + [INCLUDE / "mrirt.h"]
+    return any(p.stat().st_mtime > t for p in srcs)
+
+
+def build(force: bool = False, verbose: bool = False) -> pathlib.Path:
+    """Cross-compile every HIP source for gfx950 into the in-tree libmrirt.so (no GPU needed)."""
+    if force or _stale():
+        cmd = hipcc_command()
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if verbose or r.returncode != 0:
+            print(" ".join(cmd))
+            print(r.stdout + r.stderr)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed building libmrirt.so")
+    return SO_PATH
+
+
+_LIB: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    """Load libmrirt.so.  Raises if it is absent: the HIP library is the only render path."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not SO_PATH.exists():
+        raise ImportError(
+            f"{SO_PATH} is missing — the HIP extension is the product and has no fallback. "
+            "Build it with `python -c \"import __graft_entry__ as g; g.build()\"`.")
+    l = C.CDLL(str(SO_PATH))
+    vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int
+    l.mrirt_render_brats.argtypes = [C.POINTER(BratsParams), C.POINTER(vp), vp, vp, vp, i64, vp]
+    l.mrirt_render_brats_ex.argtypes = [C.POINTER(BratsParams), C.POINTER(RenderExt), C.POINTER(vp), vp, vp, vp, i64, vp, vp]
+    l.mrirt_brick_elems.argtypes = [C.POINTER(u32)]
+    l.mrirt_brick_elems.restype = i64
+    l.mrirt_brick_grid.argtypes = [vp, vp, C.POINTER(u32), u32, vp]
+    l.mrirt_unbrick_grid.argtypes = [vp, vp, C.POINTER(u32), u32, vp]
+    l.mrirt_render_volume.argtypes = [C.POINTER(VolumeParams), C.POINTER(RenderExt), vp, u32, vp, i64, vp, vp]
+    l.mrirt_render_sdf.argtypes = [C.POINTER(SdfParams), u32, u32, vp, i64, vp]
+    l.mrirt_tiles_for_rank.argtypes = [u32, u32, u32, u32, u32]
+    l.mrirt_tiles_for_rank.restype = i64
+    l.mrirt_detile.argtypes = [vp, vp, u32, u32, i64, u32, u32, u32, vp]
+    l.mrirt_inr_pack_bytes.argtypes = [C.POINTER(InrDesc)]
+    l.mrirt_inr_pack_bytes.restype = i64
+    l.mrirt_inr_pack_weights.argtypes = [C.POINTER(InrDesc), vp, vp, vp]
+    l.mrirt_inr_forward.argtypes = [C.POINTER(InrDesc), vp, vp, i64, vp, vp, vp]
+    l.mrirt_inr_predict_volume.argtypes = [C.POINTER(InrDesc), vp, C.POINTER(u32), vp, vp]
+    l.mrirt_status_string.argtypes = [i32]
+    l.mrirt_status_string.restype = C.c_char_p
+    l.mrirt_sizeof.argtypes = [u32]
+    l.mrirt_sizeof.restype = u32
+    for fn in ("mrirt_render_brats", "mrirt_render_brats_ex", "mrirt_brick_grid", "mrirt_unbrick_grid",
+               "mrirt_render_volume", "mrirt_render_sdf", "mrirt_detile", "mrirt_inr_pack_weights",
+               "mrirt_inr_forward", "mrirt_inr_predict_volume", "mrirt_abi_version", "mrirt_last_hip_error"):
+        getattr(l, fn).restype = i32
+    for which, st in enumerate((BratsParams, RenderExt, VolumeParams, SdfParams, InrDesc)):
+        if l.mrirt_sizeof(which) != C.sizeof(st):
+            raise ImportError(f"ABI mismatch: {st.__name__} is {C.sizeof(st)} B here, {l.mrirt_sizeof(which)} B in {SO_PATH}")
+    _LIB = l
+    return l
+
+
+def check(status: int, where: str) -> None:
+    if status != OK:
+        raise MrirtError(status, where)

@@ -1,0 +1,140 @@
+// Load-time grid layout conversion (linear <-> 4x4x2 bricks), tile bookkeeping and the
+// de-tiling copy of the multi-GPU framebuffer gather; plus the ABI's small utility entries.
+//
+// Reference counterparts: the upload `create_buffer + copy_from_numpy`
+// (inr/viewer/brats_viewer.py:219-230) is where a caller converts a linear grid once per case;
+// tiles/de-tiling have no reference counterpart (single device) — SURVEY.md section 8e.
+#include "mrirt_host.h"
+
+namespace mrirt {
+
+thread_local int g_last_hip_error = 0;
+
+// One thread per 16-byte (fp32) / 4-byte (u8) x-run of a brick: reads are 4 consecutive linear
+// voxels, writes are 4 consecutive bricked voxels; a wave writes 8 whole 128-B bricks.
+template <typename T, bool TO_BRICK>
+__global__ __launch_bounds__(256) void brick_kernel(const T* __restrict__ src, T* __restrict__ dst,
+                                                    GridDims lin, GridDims brk, uint32_t nbx, uint32_t nby, uint32_t nbz) {
+    const uint64_t run = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;   // (brick, yy, zz) run of 4 x-voxels
+    const uint64_t nruns = (uint64_t)nbx * nby * nbz * 8;
+    if (run >= nruns) return;
+    const uint32_t r = (uint32_t)(run & 7u);            // yy + 4*zz
+    const uint64_t b = run >> 3;
+    const uint32_t bx = (uint32_t)(b % nbx), by = (uint32_t)((b / nbx) % nby), bz = (uint32_t)(b / ((uint64_t)nbx * nby));
+    const uint32_t y = by * 4 + (r & 3u), z = bz * 2 + (r >> 2);
+    // edge bricks replicate the last voxel (never sampled: taps are clamped inside dims)
+    const uint32_t yc = min(y, lin.Y - 1), zc = min(z, lin.Z - 1);
+    const uint64_t boff = (uint64_t)bx * 32 + (uint64_t)by * brk.sY + (uint64_t)bz * brk.sZ + ((r & 3u) << 2) + ((r >> 2) << 4);
+#pragma unroll
+    for (uint32_t i = 0; i < 4; ++i) {
+        const uint32_t x = bx * 4 + i, xc = min(x, lin.X - 1);
+        const uint64_t loff = (uint64_t)xc + (uint64_t)yc * lin.sY + (uint64_t)zc * lin.sZ;
+        if constexpr (TO_BRICK) dst[boff + i] = src[loff];
+        else if (x < lin.X && y < lin.Y && z < lin.Z) dst[loff] = src[boff + i];
+    }
+}
+
+template <bool HALF>
+__global__ __launch_bounds__(256) void detile_kernel(const void* __restrict__ gathered, void* __restrict__ frame,
+                                                     uint32_t width, uint32_t height, int64_t pitch,
+                                                     uint32_t ts, uint32_t world, uint32_t tilesX, uint32_t maxLocal) {
+    const uint32_t px = blockIdx.x * 16 + (threadIdx.x & 15u), py = blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (px >= width || py >= height) return;
+    const uint32_t t = (py / ts) * tilesX + px / ts;
+    const uint32_t rank = t % world, lt = t / world;
+    const int64_t src = (((int64_t)rank * maxLocal + lt) * ts + (py % ts)) * ts + (px % ts);
+    const int64_t dst = (int64_t)py * pitch + px;
+    if constexpr (HALF) reinterpret_cast<uint2*>(frame)[dst] = reinterpret_cast<const uint2*>(gathered)[src];
+    else reinterpret_cast<float4*>(frame)[dst] = reinterpret_cast<const float4*>(gathered)[src];
+}
+
+static int brick_common(const void* src, void* dst, const uint32_t dims[3], uint32_t elem_bytes, bool toBrick, void* stream) {
+    if (!src || !dst || !dims) return MRIRT_ERR_NULL;
+    for (int k = 0; k < 3; ++k) if (dims[k] < 1) return MRIRT_ERR_DIMS;
+    if (elem_bytes != 1 && elem_bytes != 4) return MRIRT_ERR_LAYOUT;
+    GridDims lin, brk;
+    fill_grid_dims(lin, dims, MRIRT_LAYOUT_LINEAR);
+    fill_grid_dims(brk, dims, MRIRT_LAYOUT_BRICK);
+    const uint32_t nbx = (dims[0] + 3) / 4, nby = (dims[1] + 3) / 4, nbz = (dims[2] + 1) / 2;
+    const uint64_t nruns = (uint64_t)nbx * nby * nbz * 8;
+    const dim3 grid((uint32_t)((nruns + 255) / 256)), block(256);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (elem_bytes == 4) {
+        if (toBrick) hipLaunchKernelGGL((brick_kernel<uint32_t, true>), grid, block, 0, s, (const uint32_t*)src, (uint32_t*)dst, lin, brk, nbx, nby, nbz);
+        else         hipLaunchKernelGGL((brick_kernel<uint32_t, false>), grid, block, 0, s, (const uint32_t*)src, (uint32_t*)dst, lin, brk, nbx, nby, nbz);
+    } else {
+        if (toBrick) hipLaunchKernelGGL((brick_kernel<uint8_t, true>), grid, block, 0, s, (const uint8_t*)src, (uint8_t*)dst, lin, brk, nbx, nby, nbz);
+        else         hipLaunchKernelGGL((brick_kernel<uint8_t, false>), grid, block, 0, s, (const uint8_t*)src, (uint8_t*)dst, lin, brk, nbx, nby, nbz);
+    }
+    MRIRT_HIP(hipGetLastError());
+    return MRIRT_OK;
+}
+
+}  // namespace mrirt
+
+using namespace mrirt;
+
+extern "C" int64_t mrirt_brick_elems(const uint32_t dims[3]) {
+    if (!dims) return 0;
+    return (int64_t)((dims[0] + 3) / 4) * ((dims[1] + 3) / 4) * ((dims[2] + 1) / 2) * 32;
+}
+
+extern "C" int mrirt_brick_grid(const void* linear, void* bricked, const uint32_t dims[3], uint32_t elem_bytes, void* stream) {
+    return brick_common(linear, bricked, dims, elem_bytes, true, stream);
+}
+
+extern "C" int mrirt_unbrick_grid(const void* bricked, void* linear, const uint32_t dims[3], uint32_t elem_bytes, void* stream) {
+    return brick_common(bricked, linear, dims, elem_bytes, false, stream);
+}
+
+extern "C" int64_t mrirt_tiles_for_rank(uint32_t width, uint32_t height, uint32_t tileSize, uint32_t rank, uint32_t world) {
+    if (tileSize == 0 || world == 0 || rank >= world) return 0;
+    const int64_t tiles = (int64_t)((width + tileSize - 1) / tileSize) * ((height + tileSize - 1) / tileSize);
+    return tiles > rank ? (tiles - rank + world - 1) / world : 0;
+}
+
+extern "C" int mrirt_detile(const void* gathered, void* frame, uint32_t width, uint32_t height, int64_t pitch_px,
+                            uint32_t tileSize, uint32_t world, uint32_t outFormat, void* stream) {
+    if (!gathered || !frame) return MRIRT_ERR_NULL;
+    if (width == 0 || height == 0) return MRIRT_ERR_DIMS;
+    if (tileSize == 0 || world == 0 || pitch_px < (int64_t)width) return MRIRT_ERR_ARG;
+    if (outFormat > MRIRT_OUT_RGBA16F) return MRIRT_ERR_LAYOUT;
+    const uint32_t tilesX = (width + tileSize - 1) / tileSize;
+    const uint32_t maxLocal = (uint32_t)mrirt_tiles_for_rank(width, height, tileSize, 0, world);
+    const dim3 grid((width + 15) / 16, (height + 15) / 16), block(256);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (outFormat == MRIRT_OUT_RGBA16F)
+        hipLaunchKernelGGL((detile_kernel<true>), grid, block, 0, s, gathered, frame, width, height, pitch_px, tileSize, world, tilesX, maxLocal);
+    else
+        hipLaunchKernelGGL((detile_kernel<false>), grid, block, 0, s, gathered, frame, width, height, pitch_px, tileSize, world, tilesX, maxLocal);
+    MRIRT_HIP(hipGetLastError());
+    return MRIRT_OK;
+}
+
+extern "C" int mrirt_abi_version(void) { return MRIRT_ABI_VERSION; }
+
+extern "C" const char* mrirt_status_string(int status) {
+    switch (status) {
+        case MRIRT_OK: return "ok";
+        case MRIRT_ERR_NULL: return "required pointer is NULL";
+        case MRIRT_ERR_DIMS: return "bad volume or image dimensions";
+        case MRIRT_ERR_LAYOUT: return "unknown layout / dtype / mode";
+        case MRIRT_ERR_LAUNCH: return "HIP runtime error (see mrirt_last_hip_error)";
+        case MRIRT_ERR_ARG: return "inconsistent argument";
+        case MRIRT_ERR_NO_DEVICE: return "no gfx950 device";
+        default: return "unknown status";
+    }
+}
+
+extern "C" int mrirt_last_hip_error(void) { return g_last_hip_error; }
+
+extern "C" uint32_t mrirt_sizeof(uint32_t which) {
+    switch (which) {
+        case 0: return (uint32_t)sizeof(MrirtBratsParams);
+        case 1: return (uint32_t)sizeof(MrirtRenderExt);
+        case 2: return (uint32_t)sizeof(MrirtVolumeParams);
+        case 3: return (uint32_t)sizeof(MrirtSdfParams);
+        case 4: return (uint32_t)sizeof(MrirtInrDesc);
+        default: return 0;
+    }
+}

@@ -1,0 +1,166 @@
+// Device-side helpers shared by the gfx950 kernels: fp32 math in two flavours, ray generation,
+// brick addressing, block->pixel mapping.  Compiled with -ffp-contract=off so that the STRICT
+// flavour is unfused IEEE fp32 in the order the reference shaders write it; the FAST flavour
+// asks for FMA explicitly.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mrirt {
+
+constexpr int kWave = 64;          // CDNA wavefront
+constexpr int kTilePx = 8;         // one wave = 8x8 pixels (the reference's numthreads(8,8,1) group)
+constexpr int kBlockPx = 16;       // one 256-thread workgroup = 2x2 waves = 16x16 pixels
+constexpr int kXcds = 8;
+
+// ---------------------------------------------------------------------------------------
+// math
+// ---------------------------------------------------------------------------------------
+template <bool STRICT> struct M;
+
+template <> struct M<true> {
+    // unfused, correctly rounded: mirrors oracle_c.c / oracle_np.py exactly
+    static __device__ __forceinline__ float lerp(float a, float b, float t) { return a + t * (b - a); }
+    static __device__ __forceinline__ float exp(float x) { return (float)::exp((double)x); }
+    static __device__ __forceinline__ float pow(float x, float y) {
+        return y == 1.0f ? x : (float)::pow((double)x, (double)y);   // pow(x,1) == x exactly
+    }
+    static __device__ __forceinline__ float div(float a, float b) { return a / b; }  // IEEE (hipcc default)
+    static __device__ __forceinline__ float mad(float a, float b, float c) { return a * b + c; }
+};
+
+template <> struct M<false> {
+    static __device__ __forceinline__ float lerp(float a, float b, float t) { return __builtin_fmaf(t, b - a, a); }
+    static __device__ __forceinline__ float exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+    static __device__ __forceinline__ float pow(float x, float y) {
+        return y == 1.0f ? x : (x > 0.0f ? __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)) : 0.0f);
+    }
+    static __device__ __forceinline__ float div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+    static __device__ __forceinline__ float mad(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+};
+
+__device__ __forceinline__ float satf(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
+__device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+__device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
+    return (ax * bx + ay * by) + az * bz;
+}
+__device__ __forceinline__ void normalize3(float& x, float& y, float& z) {
+    float n = sqrtf(dot3(x, y, z, x, y, z));
+    x = x / n; y = y / n; z = z / n;
+}
+
+// ---------------------------------------------------------------------------------------
+// camera block shared by the three kernels (host fills it; invTanHalf/tanHalf are computed
+// on the host as (float)tan((double)(0.5f*fovY)) so both flavours agree with the oracle)
+// ---------------------------------------------------------------------------------------
+struct Camera {
+    float eye[3], U[3], V[3], W[3];
+    float invTanHalf;      // 1 / tan(0.5 fovY)            (K1, K3)
+    float tanHalf;         // tan(0.5 fovY)                (K2)
+    float aspect;          // W / max(1,H)   (K3: W / H)
+    float orthoHalfHeight;
+    uint32_t mode;         // 0 perspective, 1 orthographic
+    uint32_t width, height;
+};
+
+// Perspective ray of brats_rt.slang:36-46 / raymarch.slang:45-58 (or the orthographic extension).
+__device__ __forceinline__ void primary_ray(const Camera& c, uint32_t px, uint32_t py,
+                                            float ro[3], float rd[3]) {
+    float dimx = (float)c.width, dimy = (float)c.height;
+    float uvx = (((float)px + 0.5f) / dimx) * 2.0f - 1.0f;
+    float uvy = (((float)py + 0.5f) / dimy) * 2.0f - 1.0f;
+    if (c.mode == 0) {
+        float f = c.invTanHalf;
+        float cx = uvx * c.aspect / f, cy = -uvy / f, cz = 1.0f;
+        normalize3(cx, cy, cz);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { ro[k] = c.eye[k]; rd[k] = (cx * c.U[k] + cy * c.V[k]) + cz * c.W[k]; }
+        normalize3(rd[0], rd[1], rd[2]);
+    } else {
+        float sx = uvx * c.orthoHalfHeight * c.aspect, sy = -uvy * c.orthoHalfHeight;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { ro[k] = (c.eye[k] + c.U[k] * sx) + c.V[k] * sy; rd[k] = c.W[k]; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// grid addressing.  Both layouts are separable: off(x,y,z) = ox(x) + oy(y) + oz(z).
+// BRICK: 4x4x2-voxel bricks (32 elements = one 128-B line of fp32), bricks in x-fastest order.
+// ---------------------------------------------------------------------------------------
+struct GridDims {
+    uint32_t X, Y, Z;
+    uint32_t sY, sZ;       // LINEAR: X, X*Y.          BRICK: NBX*32, NBX*NBY*32
+};
+
+template <int LAYOUT> struct Addr;
+template <> struct Addr<0> {
+    static __device__ __forceinline__ uint32_t ox(const GridDims&, uint32_t x) { return x; }
+    static __device__ __forceinline__ uint32_t oy(const GridDims& g, uint32_t y) { return y * g.sY; }
+    static __device__ __forceinline__ uint32_t oz(const GridDims& g, uint32_t z) { return z * g.sZ; }
+};
+template <> struct Addr<1> {
+    static __device__ __forceinline__ uint32_t ox(const GridDims&, uint32_t x) { return ((x >> 2) << 5) + (x & 3u); }
+    static __device__ __forceinline__ uint32_t oy(const GridDims& g, uint32_t y) { return (y >> 2) * g.sY + ((y & 3u) << 2); }
+    static __device__ __forceinline__ uint32_t oz(const GridDims& g, uint32_t z) { return (z >> 1) * g.sZ + ((z & 1u) << 4); }
+};
+
+// ---------------------------------------------------------------------------------------
+// workgroup -> pixel mapping, XCD-aware, with optional tile sharding
+// ---------------------------------------------------------------------------------------
+struct PixelMap {
+    uint32_t width, height;
+    uint32_t blocksX, numBlocks;       // 16x16-pixel workgroups over the part of the image this call renders
+    uint32_t chunk;                    // ceil(numBlocks / 8): logical ids one XCD owns
+    uint32_t tileSize, tileRank, tileWorld, tilesX;   // tileWorld <= 1: whole frame
+    int64_t  pitch;                    // pixels per output row (whole-frame mode)
+};
+
+// Workgroups are dealt round-robin over the 8 XCDs (b % 8 = XCD group), so logical id
+// (b % 8) * chunk + b / 8 hands each XCD's L2 a contiguous run of neighbouring ray packets.
+// Grid is chunk*8 workgroups.  Returns 0: this lane has no pixel (whole workgroups past
+// numBlocks, or whole-frame lanes beyond the image edge); 1: march pixel (px,py) and store at
+// outIndex; 2: (tile mode) a compact-buffer slot outside the image: store background only.
+__device__ __forceinline__ int map_pixel(const PixelMap& m, uint32_t& px, uint32_t& py, int64_t& outIndex) {
+    uint32_t b = blockIdx.x;
+    uint32_t logical = (b % kXcds) * m.chunk + b / kXcds;
+    if (logical >= m.numBlocks) return 0;
+    uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    uint32_t lx = ((wave & 1u) << 3) + (lane & 7u), ly = ((wave >> 1) << 3) + (lane >> 3);
+    if (m.tileWorld <= 1) {
+        uint32_t bx = logical % m.blocksX, by = logical / m.blocksX;
+        px = bx * kBlockPx + lx; py = by * kBlockPx + ly;
+        outIndex = (int64_t)py * m.pitch + px;
+    } else {
+        uint32_t bpr = m.tileSize / kBlockPx, bpt = bpr * bpr;
+        uint32_t lt = logical / bpt, sb = logical % bpt;
+        uint32_t t = m.tileRank + lt * m.tileWorld;
+        uint32_t tx = t % m.tilesX, ty = t / m.tilesX;
+        uint32_t ix = (sb % bpr) * kBlockPx + lx, iy = (sb / bpr) * kBlockPx + ly;
+        px = tx * m.tileSize + ix; py = ty * m.tileSize + iy;
+        outIndex = ((int64_t)lt * m.tileSize + iy) * m.tileSize + ix;
+        // slots of an edge tile that fall outside the image are written as background so the
+        // compact buffer is fully defined; de-tiling drops them.
+        return (px < m.width && py < m.height) ? 1 : 2;
+    }
+    return (px < m.width && py < m.height) ? 1 : 0;
+}
+
+// RGBA store, fp32 or the reference's rgba16_float
+template <bool HALF>
+__device__ __forceinline__ void store_rgba(void* out, int64_t idx, float r, float g, float b, float a) {
+    if constexpr (HALF) {
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        h4 v = { (_Float16)r, (_Float16)g, (_Float16)b, (_Float16)a };
+        reinterpret_cast<h4*>(out)[idx] = v;
+    } else {
+        reinterpret_cast<float4*>(out)[idx] = make_float4(r, g, b, a);
+    }
+}
+
+__device__ __forceinline__ void wave_count_add(uint64_t* counter, uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63u) == 0 && v) atomicAdd(reinterpret_cast<unsigned long long*>(counter), (unsigned long long)v);
+}
+
+}  // namespace mrirt

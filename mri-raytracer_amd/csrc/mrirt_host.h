@@ -1,0 +1,78 @@
+// Host-side helpers of libmrirt.so: status/error plumbing, camera + pixel-map setup.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/mrirt.h"
+#include "mrirt_device.h"
+
+namespace mrirt {
+
+extern thread_local int g_last_hip_error;
+
+inline int hip_fail(hipError_t e) {
+    g_last_hip_error = (int)e;
+    return MRIRT_ERR_LAUNCH;
+}
+
+#define MRIRT_HIP(expr)                                         \
+    do {                                                        \
+        hipError_t e_ = (expr);                                 \
+        if (e_ != hipSuccess) return ::mrirt::hip_fail(e_);     \
+    } while (0)
+
+// correctly rounded fp32 tan: same expression as the oracle's tanf_cr(0.5f * fovY)
+inline float tan_half_fov(float fovY) { return (float)tan((double)(0.5f * fovY)); }
+
+inline void fill_camera(Camera& c, const float eye[3], const float U[3], const float V[3], const float W[3],
+                        float fovY, uint32_t width, uint32_t height, const MrirtRenderExt* ext, bool k3Aspect) {
+    for (int k = 0; k < 3; ++k) { c.eye[k] = eye[k]; c.U[k] = U[k]; c.V[k] = V[k]; c.W[k] = W[k]; }
+    float th = tan_half_fov(fovY);
+    c.tanHalf = th;
+    c.invTanHalf = 1.0f / th;
+    float dimx = (float)width, dimy = (float)height;
+    c.aspect = k3Aspect ? dimx / dimy : dimx / fmaxf(1.0f, dimy);
+    c.mode = ext ? ext->cameraMode : 0u;
+    c.orthoHalfHeight = ext ? ext->orthoHalfHeight : 0.0f;
+    c.width = width;
+    c.height = height;
+}
+
+// returns MRIRT_OK or an error; grid size = map.chunk * 8 workgroups of 256 threads
+inline int fill_pixel_map(PixelMap& m, uint32_t width, uint32_t height, int64_t pitch, const MrirtRenderExt* ext) {
+    if (width == 0 || height == 0) return MRIRT_ERR_DIMS;
+    m.width = width; m.height = height; m.pitch = pitch;
+    m.tileSize = ext ? ext->tileSize : 0u;
+    m.tileRank = ext ? ext->tileRank : 0u;
+    m.tileWorld = ext ? ext->tileWorld : 0u;
+    if (m.tileWorld <= 1) {
+        if (pitch < (int64_t)width) return MRIRT_ERR_ARG;
+        m.tilesX = 0;
+        m.blocksX = (width + kBlockPx - 1) / kBlockPx;
+        m.numBlocks = m.blocksX * ((height + kBlockPx - 1) / kBlockPx);
+    } else {
+        if (m.tileSize == 0 || m.tileSize % kBlockPx != 0 || m.tileRank >= m.tileWorld) return MRIRT_ERR_ARG;
+        m.tilesX = (width + m.tileSize - 1) / m.tileSize;
+        int64_t local = mrirt_tiles_for_rank(width, height, m.tileSize, m.tileRank, m.tileWorld);
+        uint32_t bpr = m.tileSize / kBlockPx;
+        m.blocksX = 0;
+        m.numBlocks = (uint32_t)local * bpr * bpr;
+    }
+    m.chunk = (m.numBlocks + kXcds - 1) / kXcds;
+    return MRIRT_OK;
+}
+
+inline void fill_grid_dims(GridDims& g, const uint32_t dims[3], uint32_t layout) {
+    g.X = dims[0]; g.Y = dims[1]; g.Z = dims[2];
+    if (layout == MRIRT_LAYOUT_LINEAR) {
+        g.sY = dims[0];
+        g.sZ = dims[0] * dims[1];
+    } else {
+        uint32_t nbx = (dims[0] + 3) / 4, nby = (dims[1] + 3) / 4;
+        g.sY = nbx * 32;
+        g.sZ = nbx * nby * 32;
+    }
+}
+
+}  // namespace mrirt

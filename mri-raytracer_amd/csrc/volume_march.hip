@@ -1,0 +1,201 @@
+// K2: fixed-step near/far-plane volume marcher — gfx950 HIP replacement for the Slang compute
+// shader `volume_cs` (reference: scripts/volumeRendering/volume_render.slang:104-148; sampling
+// helpers :28-65).  K3: analytic-SDF sphere tracer `raymarch_cs`
+// (scripts/raymarch/raymarch.slang:60-99).
+//
+// K2 voxel modes: the reference's one-u32-per-u8-voxel uint4 buffer (app.py:150-153), real
+// bytes, or fp32 (build-defined generalisation used by BASELINE config 1).
+#include "mrirt_host.h"
+
+namespace mrirt {
+
+struct K2Args {
+    Camera cam;
+    PixelMap map;
+    uint32_t dim[3];
+    float dimM1[3];        // float(d) - 1
+    float nearP, farP;     // already max(0,near), max(near,far)
+    float steps;           // max(1, stepCount)
+    const void* vol;
+    void* out;
+    uint64_t* stats;
+};
+
+template <int MODE>
+__device__ __forceinline__ float fetch_k2(const void* __restrict__ vol, uint32_t idx) {
+    if constexpr (MODE == 0) return (float)(static_cast<const uint32_t*>(vol)[idx] & 0xffu) / 255.0f;  // :33-38
+    else if constexpr (MODE == 1) return (float)static_cast<const uint8_t*>(vol)[idx] / 255.0f;
+    else return static_cast<const float*>(vol)[idx];
+}
+
+template <bool STRICT, int MODE, bool HALF>
+__global__ __launch_bounds__(256) void volume_march_kernel(const K2Args a) {
+    using Mm = M<STRICT>;
+    uint32_t px, py;
+    int64_t oidx;
+    const int kind = map_pixel(a.map, px, py, oidx);
+    if (a.map.numBlocks == 0) return;
+    float accum = 0.0f;
+    uint32_t nLive = 0;
+    if (kind == 1) {
+        const Camera& c = a.cam;
+        const float invx = 1.0f / (float)c.width, invy = 1.0f / (float)c.height;
+        const float uvx = ((float)px + 0.5f) * invx, uvy = ((float)py + 0.5f) * invy;
+        const float ndcx = uvx * 2.0f - 1.0f, ndcy = 1.0f - uvy * 2.0f;
+        const float n = a.nearP, f = a.farP;
+        float pos[3], sv[3];
+        if (c.mode == 0) {
+            const float vx = ndcx * c.aspect * c.tanHalf, vy = ndcy * c.tanHalf, vz = 1.0f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float wn = ((c.eye[k] + c.U[k] * (vx * n)) + c.V[k] * (vy * n)) + c.W[k] * (vz * n);
+                const float wf = ((c.eye[k] + c.U[k] * (vx * f)) + c.V[k] * (vy * f)) + c.W[k] * (vz * f);
+                pos[k] = wn; sv[k] = (wf - wn) / a.steps;
+            }
+        } else {
+            const float sx = ndcx * c.aspect * c.orthoHalfHeight, sy = ndcy * c.orthoHalfHeight;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float wn = ((c.eye[k] + c.U[k] * sx) + c.V[k] * sy) + c.W[k] * n;
+                const float wf = ((c.eye[k] + c.U[k] * sx) + c.V[k] * sy) + c.W[k] * f;
+                pos[k] = wn; sv[k] = (wf - wn) / a.steps;
+            }
+        }
+        const float scale = 4.0f / a.steps;
+        const uint32_t nsteps = (uint32_t)a.steps;
+        const uint32_t sY = a.dim[0], sZ = a.dim[0] * a.dim[1];
+        for (uint32_t i = 0; i < nsteps; ++i) {
+            const bool inside = pos[0] < 1.0f && pos[1] < 1.0f && pos[2] < 1.0f &&
+                                pos[0] > -1.0f && pos[1] > -1.0f && pos[2] > -1.0f;
+            if (inside && accum < 1.0f) {
+                uint32_t p0[3], p1[3];
+                float t[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float x = satf(0.5f * (pos[k] + 1.0f)) * a.dimM1[k];
+                    const float fl = floorf(x);
+                    p0[k] = (uint32_t)fl;
+                    p1[k] = min(p0[k] + 1, a.dim[k] - 1);
+                    t[k] = x - fl;
+                }
+                const uint32_t y0 = p0[1] * sY, y1 = p1[1] * sY, z0 = p0[2] * sZ, z1 = p1[2] * sZ;
+                const float c000 = fetch_k2<MODE>(a.vol, p0[0] + y0 + z0), c100 = fetch_k2<MODE>(a.vol, p1[0] + y0 + z0);
+                const float c010 = fetch_k2<MODE>(a.vol, p0[0] + y1 + z0), c110 = fetch_k2<MODE>(a.vol, p1[0] + y1 + z0);
+                const float c001 = fetch_k2<MODE>(a.vol, p0[0] + y0 + z1), c101 = fetch_k2<MODE>(a.vol, p1[0] + y0 + z1);
+                const float c011 = fetch_k2<MODE>(a.vol, p0[0] + y1 + z1), c111 = fetch_k2<MODE>(a.vol, p1[0] + y1 + z1);
+                const float c00 = Mm::lerp(c000, c100, t[0]), c01 = Mm::lerp(c001, c101, t[0]);
+                const float c10 = Mm::lerp(c010, c110, t[0]), c11 = Mm::lerp(c011, c111, t[0]);
+                const float c0 = Mm::lerp(c00, c10, t[1]), c1 = Mm::lerp(c01, c11, t[1]);
+                const float s = Mm::lerp(c0, c1, t[2]) * scale;
+                accum = Mm::mad(1.0f - accum, s, accum);
+                ++nLive;
+            }
+            pos[0] += sv[0]; pos[1] += sv[1]; pos[2] += sv[2];      // incremental, as the shader (:143)
+            if (accum > 0.995f) break;
+        }
+    }
+    if (kind != 0) store_rgba<HALF>(a.out, oidx, accum, accum, accum, 1.0f);
+    if (a.stats != nullptr) wave_count_add(a.stats, nLive);
+}
+
+template <bool STRICT, int MODE>
+static int launch_k2(const K2Args& a, bool half, hipStream_t s) {
+    const dim3 grid(a.map.chunk * kXcds), block(256);
+    if (half) hipLaunchKernelGGL((volume_march_kernel<STRICT, MODE, true>), grid, block, 0, s, a);
+    else      hipLaunchKernelGGL((volume_march_kernel<STRICT, MODE, false>), grid, block, 0, s, a);
+    MRIRT_HIP(hipGetLastError());
+    return MRIRT_OK;
+}
+
+template <bool STRICT>
+static int launch_k2_mode(const K2Args& a, uint32_t mode, bool half, hipStream_t s) {
+    switch (mode) {
+        case MRIRT_VOX_U32X4: return launch_k2<STRICT, 0>(a, half, s);
+        case MRIRT_VOX_U8: return launch_k2<STRICT, 1>(a, half, s);
+        default: return launch_k2<STRICT, 2>(a, half, s);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// K3
+// ---------------------------------------------------------------------------------------
+struct K3Args {
+    Camera cam;
+    PixelMap map;
+    uint32_t maxSteps;
+    float maxDistance, hitThreshold;
+    float* out;
+};
+
+__global__ __launch_bounds__(256) void sdf_march_kernel(const K3Args a) {
+    uint32_t px, py;
+    int64_t oidx;
+    if (map_pixel(a.map, px, py, oidx) != 1) return;
+    float ro[3], rd[3];
+    primary_ray(a.cam, px, py, ro, rd);
+    float t = 0.0f, p[3] = { ro[0], ro[1], ro[2] };
+    bool hit = false;
+    for (uint32_t i = 0; i < a.maxSteps; ++i) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) p[k] = ro[k] + t * rd[k];
+        const float d = sqrtf(dot3(p[0], p[1], p[2], p[0], p[1], p[2])) - 0.6f;   // sdSphere(p, 0.6), :24-31
+        if (d < a.hitThreshold) { hit = true; break; }
+        t += clampf(d, 0.01f, 0.25f);
+        if (t > a.maxDistance) break;
+    }
+    float r, g, b;
+    if (hit) {
+        float nx = p[0], ny = p[1], nz = p[2];
+        normalize3(nx, ny, nz);
+        const float u = (float)atan2((double)nz, (double)nx) / (2.0f * 3.14159265f) + 0.5f;
+        r = u; g = ny * 0.5f + 0.5f; b = 1.0f - u;
+    } else {
+        float dx = rd[0], dy = rd[1], dz = rd[2];
+        normalize3(dx, dy, dz);
+        const float tbg = 0.5f * (dy + 1.0f);
+        r = M<true>::lerp(0.05f, 0.2f, tbg); g = M<true>::lerp(0.06f, 0.25f, tbg); b = M<true>::lerp(0.08f, 0.3f, tbg);
+    }
+    reinterpret_cast<float4*>(a.out)[oidx] = make_float4(r, g, b, 1.0f);
+}
+
+}  // namespace mrirt
+
+using namespace mrirt;
+
+extern "C" int mrirt_render_volume(const MrirtVolumeParams* p, const MrirtRenderExt* ext, const void* volume,
+                                   uint32_t mode, void* out_rgba, int64_t pitch_px, uint64_t* stats_dev, void* stream) {
+    if (!p || !volume || !out_rgba) return MRIRT_ERR_NULL;
+    if (mode > MRIRT_VOX_F32) return MRIRT_ERR_LAYOUT;
+    for (int k = 0; k < 3; ++k) if (p->volDim[k] < 1) return MRIRT_ERR_DIMS;
+    if ((uint64_t)p->volDim[0] * p->volDim[1] * p->volDim[2] >= (1ull << 32)) return MRIRT_ERR_DIMS;
+    const uint32_t math = ext ? ext->math : (uint32_t)MRIRT_MATH_STRICT;
+    const uint32_t fmt = ext ? ext->outFormat : (uint32_t)MRIRT_OUT_RGBA32F;
+    if (math > MRIRT_MATH_FAST || fmt > MRIRT_OUT_RGBA16F) return MRIRT_ERR_LAYOUT;
+    K2Args a;
+    fill_camera(a.cam, p->eye, p->U, p->V, p->W, p->fovY, p->imageSize[0], p->imageSize[1], ext, false);
+    int rc = fill_pixel_map(a.map, p->imageSize[0], p->imageSize[1], pitch_px, ext);
+    if (rc != MRIRT_OK) return rc;
+    for (int k = 0; k < 3; ++k) { a.dim[k] = p->volDim[k]; a.dimM1[k] = (float)p->volDim[k] - 1.0f; }
+    a.nearP = fmaxf(0.0f, p->nearPlane);
+    a.farP = fmaxf(a.nearP, p->farPlane);
+    a.steps = fmaxf(1.0f, p->stepCount);
+    a.vol = volume; a.out = out_rgba; a.stats = stats_dev;
+    if (a.map.numBlocks == 0) return MRIRT_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool half = fmt == MRIRT_OUT_RGBA16F;
+    return math == MRIRT_MATH_STRICT ? launch_k2_mode<true>(a, mode, half, s) : launch_k2_mode<false>(a, mode, half, s);
+}
+
+extern "C" int mrirt_render_sdf(const MrirtSdfParams* p, uint32_t width, uint32_t height,
+                                float* out_rgba, int64_t pitch_px, void* stream) {
+    if (!p || !out_rgba) return MRIRT_ERR_NULL;
+    K3Args a;
+    fill_camera(a.cam, p->gEye, p->gU, p->gV, p->gW, p->fovY, width, height, nullptr, true);
+    int rc = fill_pixel_map(a.map, width, height, pitch_px, nullptr);
+    if (rc != MRIRT_OK) return rc;
+    a.maxSteps = p->maxSteps; a.maxDistance = p->maxDistance; a.hitThreshold = p->hitThreshold;
+    a.out = out_rgba;
+    hipLaunchKernelGGL(sdf_march_kernel, dim3(a.map.chunk * kXcds), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    MRIRT_HIP(hipGetLastError());
+    return MRIRT_OK;
+}

@@ -1,0 +1,238 @@
+"""Render entry points over the C ABI: render_brats / render_volume_u8 / render_sdf.
+
+torch is used for device memory and the current HIP stream only; every pixel is produced by
+the hand-written gfx950 kernels in csrc/ (reached through libmrirt.so).  There is no CPU path:
+without a GPU (or without the built library) these functions raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Any, Dict, Mapping, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+
+from . import _lib
+from .params import brats_params, render_ext, sdf_params, volume_params
+
+ArrayLike = Union[np.ndarray, torch.Tensor]
+
+
+def _require_gpu() -> torch.device:
+    if not torch.cuda.is_available():
+        raise RuntimeError("mrirt: no HIP device visible — the ray-marcher has no CPU fallback "
+                           "(the CPU restatement under oracle/ is test infrastructure only)")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _stream_ptr(stream) -> C.c_void_p:
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return C.c_void_p(s.cuda_stream if hasattr(s, "cuda_stream") else int(s))
+
+
+def _ptr(t: Optional[torch.Tensor]) -> C.c_void_p:
+    return C.c_void_p(t.data_ptr() if t is not None else None)
+
+
+@dataclass
+class Grid:
+    """A device-resident voxel grid: the analogue of the reference's StructuredBuffer created by
+    ``device.create_buffer`` + ``copy_from_numpy`` (inr/viewer/brats_viewer.py:219-230)."""
+    data: torch.Tensor            # 1-D, device
+    dims: Tuple[int, int, int]    # (X, Y, Z), x fastest in the linear layout
+    layout: str = "linear"        # "linear" | "brick"
+
+    @property
+    def nbytes(self) -> int:
+        return self.data.numel() * self.data.element_size()
+
+
+def brick_elems(dims: Sequence[int]) -> int:
+    d = (C.c_uint32 * 3)(*[int(v) for v in dims])
+    return int(_lib.lib().mrirt_brick_elems(d))
+
+
+def upload_grid(linear: ArrayLike, dims: Sequence[int], layout: str = "brick", stream=None) -> Grid:
+    """Upload a linear (x-fastest) fp32 / uint32 / uint8 grid and, for ``layout='brick'``,
+    re-brick it on the device (csrc/grid_ops.hip).  Load-time, once per volume."""
+    dev = _require_gpu()
+    dims = tuple(int(v) for v in dims)
+    t = torch.as_tensor(linear).reshape(-1)
+    if t.dtype not in (torch.float32, torch.uint8, torch.int32, torch.uint32):
+        if t.dtype in (torch.int64, torch.uint16, torch.int16):
+            t = t.to(torch.int32)
+        else:
+            t = t.to(torch.float32)
+    if t.numel() != dims[0] * dims[1] * dims[2]:
+        raise ValueError(f"grid has {t.numel()} voxels, dims {dims} need {dims[0] * dims[1] * dims[2]}")
+    t = t.to(dev).contiguous()
+    if layout == "linear":
+        return Grid(t, dims, "linear")
+    if layout != "brick":
+        raise ValueError(f"unknown layout {layout!r}")
+    out = torch.empty(brick_elems(dims), dtype=t.dtype, device=dev)
+    d = (C.c_uint32 * 3)(*dims)
+    _lib.check(_lib.lib().mrirt_brick_grid(_ptr(t), _ptr(out), d, t.element_size(), _stream_ptr(stream)),
+               "mrirt_brick_grid")
+    return Grid(out, dims, "brick")
+
+
+def unbrick_grid(g: Grid, stream=None) -> torch.Tensor:
+    if g.layout == "linear":
+        return g.data
+    out = torch.empty(g.dims[0] * g.dims[1] * g.dims[2], dtype=g.data.dtype, device=g.data.device)
+    d = (C.c_uint32 * 3)(*g.dims)
+    _lib.check(_lib.lib().mrirt_unbrick_grid(_ptr(g.data), _ptr(out), d, g.data.element_size(), _stream_ptr(stream)),
+               "mrirt_unbrick_grid")
+    return out
+
+
+def _as_device_tensor(x, dtype, dev, what: str) -> Optional[torch.Tensor]:
+    if x is None:
+        return None
+    if isinstance(x, Grid):
+        x = x.data
+    t = torch.as_tensor(x)
+    if t.dtype != dtype:
+        if dtype == torch.int32 and t.dtype in (torch.uint32, torch.int64, torch.uint8, torch.int16):
+            t = t.to(torch.int64).to(torch.int32) if t.dtype == torch.uint32 else t.to(torch.int32)
+        elif dtype == torch.float32 and t.is_floating_point():
+            t = t.to(torch.float32)
+        else:
+            raise TypeError(f"{what}: expected {dtype}, got {t.dtype}")
+    return t.to(dev).contiguous().reshape(-1)
+
+
+def tiles_for_rank(width: int, height: int, tile: int, rank: int, world: int) -> int:
+    return int(_lib.lib().mrirt_tiles_for_rank(width, height, tile, rank, world))
+
+
+def _alloc_out(params_w: int, params_h: int, ext: _lib.RenderExt, dev, out):
+    dt = torch.float16 if ext.outFormat == _lib.OUT_RGBA16F else torch.float32
+    if ext.tileWorld > 1:
+        n = tiles_for_rank(params_w, params_h, ext.tileSize, ext.tileRank, ext.tileWorld)
+        shape = (n, ext.tileSize, ext.tileSize, 4)
+    else:
+        shape = (params_h, params_w, 4)
+    if out is None:
+        return torch.empty(shape, dtype=dt, device=dev), params_w
+    if out.dtype != dt or not out.is_cuda or out.stride(-1) != 1:
+        raise TypeError(f"out: expected a device {dt} tensor with unit channel stride")
+    if ext.tileWorld > 1:
+        if tuple(out.shape) != shape or not out.is_contiguous():
+            raise ValueError(f"out: expected contiguous {shape}")
+        return out, params_w
+    if out.shape[0] < params_h or out.shape[1] < params_w or out.shape[2] != 4 or out.stride(1) != 4:
+        raise ValueError(f"out: expected at least ({params_h},{params_w},4) with pixel stride 4")
+    return out, out.stride(0) // 4
+
+
+def render_brats(params: Mapping[str, Any], intensities: Sequence[Optional[Union[ArrayLike, Grid]]],
+                 labels: Optional[Union[ArrayLike, Grid]] = None, preds: Optional[Union[ArrayLike, Grid]] = None,
+                 out: Optional[torch.Tensor] = None, ext: Optional[Mapping[str, Any]] = None,
+                 stats: bool = False, stream=None):
+    """K1 — drop-in for ``kernel.dispatch`` of ``brats_main`` (inr/viewer/brats_viewer.py:431-442).
+
+    ``params`` is the reference's ``gParams`` dict; ``intensities`` are ``gIntensity0..3``,
+    ``labels``/``preds`` are ``gLabels``/``gPreds``.  Returns the fp32 (H,W,4) frame (or the
+    compact tile buffer when ``ext`` shards tiles).  With ``stats=True`` also returns
+    ``{"live_samples", "shaded_samples"}`` counted on the device.
+    """
+    dev = _require_gpu()
+    P = brats_params(params)
+    e = dict(ext or {})
+    grids = [g for g in list(intensities) + [labels, preds] if isinstance(g, Grid)]
+    if grids and "layout" not in e:
+        e["layout"] = grids[0].layout
+    E = render_ext(e)
+    lay = "brick" if E.layout == _lib.LAYOUT_BRICK else "linear"
+    for g in grids:
+        if g.layout != lay:
+            raise ValueError(f"all bound grids must share one layout ({lay}); got {g.layout}")
+        if tuple(g.dims) != tuple(int(v) for v in P.dims):
+            raise ValueError(f"grid dims {g.dims} != gParams.dims {tuple(P.dims)}")
+    nvox = int(P.dims[0]) * int(P.dims[1]) * int(P.dims[2])
+    need = brick_elems(tuple(P.dims)) if lay == "brick" else nvox
+    vols = []
+    for m in range(4):
+        v = intensities[m] if m < len(intensities) else None
+        t = _as_device_tensor(v, torch.float32, dev, f"gIntensity{m}")
+        if P.volEnabled[m] != 0:
+            if t is None or t.numel() < need:
+                raise ValueError(f"gIntensity{m} is enabled but holds {0 if t is None else t.numel()} < {need} voxels")
+        vols.append(t)
+    lab = _as_device_tensor(labels, torch.int32, dev, "gLabels")
+    prd = _as_device_tensor(preds, torch.int32, dev, "gPreds")
+    if P.showSeg != 0 and (lab is None or lab.numel() < need):
+        raise ValueError("showSeg is set but gLabels is missing or too small")
+    if P.showPred != 0 and (prd is None or prd.numel() < need):
+        raise ValueError("showPred is set but gPreds is missing or too small")
+    o, pitch = _alloc_out(int(P.imageSize[0]), int(P.imageSize[1]), E, dev, out)
+    vp = (C.c_void_p * 4)(*[C.c_void_p(t.data_ptr()) if t is not None else None for t in vols])
+    st = torch.zeros(2, dtype=torch.int64, device=dev) if stats else None
+    rc = _lib.lib().mrirt_render_brats_ex(C.byref(P), C.byref(E), vp, _ptr(lab), _ptr(prd), _ptr(o),
+                                          pitch, _ptr(st), _stream_ptr(stream))
+    _lib.check(rc, "mrirt_render_brats_ex")
+    if stats:
+        s = st.cpu()
+        return o, {"live_samples": int(s[0]), "shaded_samples": int(s[1])}
+    return o
+
+
+_VOX = {"u32x4": (_lib.VOX_U32X4, torch.int32), "u8": (_lib.VOX_U8, torch.uint8), "f32": (_lib.VOX_F32, torch.float32)}
+
+
+def render_volume_u8(params: Mapping[str, Any], volume: ArrayLike, mode: str = "u32x4",
+                     out: Optional[torch.Tensor] = None, ext: Optional[Mapping[str, Any]] = None,
+                     stats: bool = False, stream=None):
+    """K2 — drop-in for ``kernel.dispatch`` of ``volume_cs`` (scripts/volumeRendering/app.py:350-358).
+    ``volume`` is ``gVolumeU8``: the (N/4,4) uint32 array of app.py:153 (``mode='u32x4'``), real
+    bytes (``'u8'``) or an fp32 grid (``'f32'``)."""
+    dev = _require_gpu()
+    P = volume_params(params)
+    E = render_ext(ext)
+    code, dt = _VOX[mode]
+    t = torch.as_tensor(volume)
+    if mode == "u32x4" and t.dtype in (torch.uint32, torch.int64):
+        t = t.to(torch.int64).to(torch.int32)
+    if t.dtype != dt:
+        raise TypeError(f"gVolumeU8 ({mode}): expected {dt}, got {t.dtype}")
+    t = t.to(dev).contiguous().reshape(-1)
+    nvox = int(P.volDim[0]) * int(P.volDim[1]) * int(P.volDim[2])
+    if t.numel() < nvox:
+        raise ValueError(f"gVolumeU8 holds {t.numel()} < {nvox} voxels")
+    o, pitch = _alloc_out(int(P.imageSize[0]), int(P.imageSize[1]), E, dev, out)
+    st = torch.zeros(2, dtype=torch.int64, device=dev) if stats else None
+    rc = _lib.lib().mrirt_render_volume(C.byref(P), C.byref(E), _ptr(t), code, _ptr(o), pitch, _ptr(st),
+                                        _stream_ptr(stream))
+    _lib.check(rc, "mrirt_render_volume")
+    if stats:
+        return o, {"live_samples": int(st.cpu()[0])}
+    return o
+
+
+def render_sdf(params: Mapping[str, Any], eye, U, V, W, width: int, height: int,
+               out: Optional[torch.Tensor] = None, stream=None) -> torch.Tensor:
+    """K3 — drop-in for ``kernel.dispatch`` of ``raymarch_cs`` (scripts/raymarch/app.py:212-223);
+    ``width``/``height`` are the render_texture's dimensions."""
+    dev = _require_gpu()
+    P = sdf_params(params, eye, U, V, W)
+    if out is None:
+        out = torch.empty((height, width, 4), dtype=torch.float32, device=dev)
+    pitch = out.stride(0) // 4
+    rc = _lib.lib().mrirt_render_sdf(C.byref(P), int(width), int(height), _ptr(out), pitch, _stream_ptr(stream))
+    _lib.check(rc, "mrirt_render_sdf")
+    return out
+
+
+def detile(gathered: torch.Tensor, width: int, height: int, tile: int, world: int,
+           out: Optional[torch.Tensor] = None, stream=None) -> torch.Tensor:
+    """[world, max_local, ts, ts, 4] compact tiles -> (H, W, 4) frame (csrc/grid_ops.hip)."""
+    half = gathered.dtype == torch.float16
+    if out is None:
+        out = torch.empty((height, width, 4), dtype=gathered.dtype, device=gathered.device)
+    rc = _lib.lib().mrirt_detile(_ptr(gathered), _ptr(out), width, height, out.stride(0) // 4, tile, world,
+                                 _lib.OUT_RGBA16F if half else _lib.OUT_RGBA32F, _stream_ptr(stream))
+    _lib.check(rc, "mrirt_detile")
+    return out

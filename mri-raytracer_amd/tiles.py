@@ -1,0 +1,95 @@
+"""Image-tile sharding across the GPUs of one node (one process per GPU) and the framebuffer
+exchange.  No reference counterpart (the reference is single-device): SURVEY.md section 8(e).
+
+Rays are independent, nothing is reduced: the W x H image is cut into ``tile`` x ``tile`` pixel
+tiles dealt round-robin (tile id mod world size) so early-terminating and empty regions spread
+evenly; the volume is replicated on every GPU (512 MiB for a 512^3 fp32 grid against 288 GB);
+each rank renders its tiles into a compact [n_local, tile, tile, 4] buffer and ONE collective
+moves them: an RCCL gather to rank 0 (``torch.distributed`` backend "nccl" is RCCL on ROCm;
+each peer's 1/N of the frame crosses its own direct xGMI link to the root), followed by a
+de-tiling copy kernel.  With the gloo backend (CPU tests) the same code path runs on host
+tensors.
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, Mapping, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+DEFAULT_TILE = 64
+
+
+def num_tiles(width: int, height: int, tile: int = DEFAULT_TILE) -> int:
+    return ((width + tile - 1) // tile) * ((height + tile - 1) // tile)
+
+
+def local_tile_count(width: int, height: int, tile: int, rank: int, world: int) -> int:
+    """Tiles rank ``rank`` owns: ids rank, rank+world, ... (same rule as mrirt_tiles_for_rank)."""
+    n = num_tiles(width, height, tile)
+    return (n - rank + world - 1) // world if n > rank else 0
+
+
+def tile_origin(tile_id: int, width: int, tile: int):
+    tiles_x = (width + tile - 1) // tile
+    return (tile_id % tiles_x) * tile, (tile_id // tiles_x) * tile      # (x0, y0)
+
+
+def shard_ext(ext: Optional[Mapping[str, Any]], rank: int, world: int, tile: int = DEFAULT_TILE) -> Dict[str, Any]:
+    """Render-extension dict that makes render_brats/render_volume_u8 produce this rank's tiles."""
+    e = dict(ext or {})
+    e.update(tileSize=tile, tileRank=rank, tileWorld=world)
+    return e
+
+
+def assemble_frame(gathered: torch.Tensor, width: int, height: int, tile: int, world: int) -> torch.Tensor:
+    """[world, max_local, tile, tile, 4] -> (H, W, 4).  Device tensors go through the HIP
+    de-tiling kernel; host tensors (gloo tests, host read-back) through plain indexing."""
+    if gathered.is_cuda:
+        from .render import detile
+        return detile(gathered.contiguous(), width, height, tile, world)
+    tiles_x, tiles_y = (width + tile - 1) // tile, (height + tile - 1) // tile
+    frame = gathered.new_empty((tiles_y * tile, tiles_x * tile, 4))
+    for t in range(tiles_x * tiles_y):
+        x0, y0 = tile_origin(t, width, tile)
+        frame[y0:y0 + tile, x0:x0 + tile] = gathered[t % world, t // world]
+    return frame[:height, :width].contiguous()
+
+
+def gather_frame(local_tiles: torch.Tensor, width: int, height: int, tile: int = DEFAULT_TILE,
+                 group=None, dst: int = 0, all_ranks: bool = False) -> Optional[torch.Tensor]:
+    """The one exchange step.  ``local_tiles`` is this rank's compact buffer; returns the full
+    frame on ``dst`` (on every rank when ``all_ranks``), None elsewhere.  Ranks may own unequal
+    tile counts (off by at most one): buffers are padded to rank 0's count for the collective."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return assemble_frame(local_tiles.unsqueeze(0), width, height, tile, 1)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    max_local = local_tile_count(width, height, tile, 0, world)
+    send = local_tiles
+    if send.shape[0] != max_local:
+        pad = send.new_zeros((max_local - send.shape[0],) + tuple(send.shape[1:]))
+        send = torch.cat([send, pad], dim=0)
+    send = send.contiguous()
+    if all_ranks:
+        buf = send.new_empty((world,) + tuple(send.shape))
+        dist.all_gather_into_tensor(buf, send, group=group)
+        return assemble_frame(buf, width, height, tile, world)
+    if rank == dst:
+        buf = send.new_empty((world,) + tuple(send.shape))
+        dist.gather(send, list(buf.unbind(0)), dst=dst, group=group)
+        return assemble_frame(buf, width, height, tile, world)
+    dist.gather(send, None, dst=dst, group=group)
+    return None
+
+
+def render_brats_sharded(params, intensities: Sequence, labels=None, preds=None, ext=None,
+                         tile: int = DEFAULT_TILE, group=None, dst: int = 0, all_ranks: bool = False):
+    """K1 across the process group: render this rank's tiles, then gather (see module docstring)."""
+    from .render import render_brats
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if world == 1:
+        return render_brats(params, intensities, labels, preds, ext=ext)
+    local = render_brats(params, intensities, labels, preds, ext=shard_ext(ext, rank, world, tile))
+    w, h = int(params["imageSize"][0]), int(params["imageSize"][1])
+    return gather_frame(local, w, h, tile, group=group, dst=dst, all_ranks=all_ranks)

@@ -1,0 +1,370 @@
+/* CPU oracle (C11 + OpenMP, scalar fp32) for the MRI ray-march hot path.
+ * TEST INFRASTRUCTURE ONLY: linked or dlopen()ed solely by tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg.  Nothing under mri-raytracer_amd/ uses it.
+ *
+ * A second, independent restatement of the same reference text as oracle_np.py (which it is
+ * tested against bit-for-bit), fast enough for BASELINE-sized inputs:
+ *   K1  inr/viewer/brats_rt.slang:12-168                         -> oracle_brats_main
+ *   K2  scripts/volumeRendering/volume_render.slang:9-65,104-148 -> oracle_volume_cs
+ *   K3  scripts/raymarch/raymarch.slang:7-99                     -> oracle_raymarch_cs
+ * Conventions are those listed in oracle_np.py's header: unfused IEEE fp32 evaluated in the
+ * order written, correctly rounded transcendentals (fp64 libm, one rounding), round-half-away
+ * in sampleLabel.  Build with -ffp-contract=off (see oracle/Makefile).
+ *
+ * Parity status: image-level parity is unpinned by the reference (no tests, Slang not
+ * runnable here); see DESIGN.md "Oracle".
+ */
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+typedef struct {
+    uint32_t width, height;
+    float fovY;
+    float eye[3], U[3], V[3], W[3];
+    float volMin[3], voxelSize[3];
+    uint32_t dims[3];
+    float stepSize, nearT, farT;
+    float bgColor[3];
+    uint32_t volEnabled[4];
+    float volWeight[4];
+    float ww, wl, intensityAlpha, gamma;
+    uint32_t showSeg, showPred;
+    float lut[8][4];
+    /* build-defined extensions (0 = reference behaviour) */
+    uint32_t cameraMode;      /* 1 = orthographic */
+    float orthoHalfHeight;
+    uint32_t shadeMode;       /* 1 = lattice-gradient Blinn-Phong headlight */
+    float ka, kd, ks;
+    uint32_t specPow2;
+    float gradEps;
+    float ertThreshold;       /* reference: 0.01 */
+} OracleBratsParams;
+
+typedef struct {
+    uint32_t width, height;
+    float fovY, stepCount, nearPlane, farPlane;
+    float eye[3], U[3], V[3], W[3];
+    uint32_t volDim[3];
+    uint32_t mode;            /* 0 = uint4-packed u8-in-u32 (reference), 1 = u8 bytes, 2 = fp32 */
+    uint32_t cameraMode;
+    float orthoHalfHeight;
+} OracleVolumeParams;
+
+typedef struct {
+    uint32_t width, height;   /* texture size */
+    float fovY;
+    uint32_t maxSteps;
+    float maxDistance, hitThreshold, normalEps;
+    float eye[3], U[3], V[3], W[3];
+} OracleSdfParams;
+
+static inline float expf_cr(float x) { return (float)exp((double)x); }
+static inline float powf_cr(float x, float y) { return (float)pow((double)x, (double)y); }
+static inline float tanf_cr(float x) { return (float)tan((double)x); }
+static inline float lerpf(float a, float b, float t) { return a + t * (b - a); }
+static inline float satf(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
+static inline float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+static inline float dot3(const float* a, const float* b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+static inline void normalize3(float* v) {
+    float n = sqrtf(dot3(v, v));
+    v[0] = v[0] / n; v[1] = v[1] / n; v[2] = v[2] / n;
+}
+
+/* brats_rt.slang:36-46 */
+static void make_primary(uint32_t px, uint32_t py, uint32_t w, uint32_t h, float fovY, int k3_aspect,
+                         const float* U, const float* V, const float* W, float* rd) {
+    float dimx = (float)w, dimy = (float)h;
+    float ndcx = ((float)px + 0.5f) / dimx, ndcy = ((float)py + 0.5f) / dimy;
+    float uvx = ndcx * 2.0f - 1.0f, uvy = ndcy * 2.0f - 1.0f;
+    float f = 1.0f / tanf_cr(0.5f * fovY);
+    float aspect = k3_aspect ? dimx / dimy : dimx / fmaxf(1.0f, dimy);
+    float c[3] = { uvx * aspect / f, -uvy / f, 1.0f };
+    normalize3(c);
+    for (int k = 0; k < 3; ++k) rd[k] = (c[0] * U[k] + c[1] * V[k]) + c[2] * W[k];
+    normalize3(rd);
+}
+
+/* sampleLinear, brats_rt.slang:60-76 */
+static inline float sample_linear(const float* buf, const float* q, const uint32_t* dims,
+                                  uint32_t* i, float* f) {
+    for (int k = 0; k < 3; ++k) {
+        float c = clampf(q[k], 0.0f, (float)dims[k] - 1.001f);
+        float fl = floorf(c);
+        i[k] = (uint32_t)fl;
+        f[k] = c - (float)i[k];
+    }
+    size_t sY = dims[0], sZ = (size_t)dims[0] * dims[1];
+    size_t b = i[0] + i[1] * sY + i[2] * sZ;
+    float c000 = buf[b], c100 = buf[b + 1];
+    float c010 = buf[b + sY], c110 = buf[b + sY + 1];
+    float c001 = buf[b + sZ], c101 = buf[b + sZ + 1];
+    float c011 = buf[b + sZ + sY], c111 = buf[b + sZ + sY + 1];
+    return lerpf(lerpf(lerpf(c000, c100, f[0]), lerpf(c010, c110, f[0]), f[1]),
+                 lerpf(lerpf(c001, c101, f[0]), lerpf(c011, c111, f[0]), f[1]), f[2]);
+}
+
+/* build-defined: trilinear blend of lattice central differences (see oracle_np._lattice_gradient) */
+static inline void lattice_gradient(const float* buf, const uint32_t* i, const float* f,
+                                    const uint32_t* dims, float* g) {
+    const int64_t X = dims[0], Y = dims[1], Z = dims[2];
+    for (int axis = 0; axis < 3; ++axis) {
+        float d[2][2][2];
+        for (int dz = 0; dz < 2; ++dz) for (int dy = 0; dy < 2; ++dy) for (int dx = 0; dx < 2; ++dx) {
+            int64_t c[3] = { (int64_t)i[0] + dx, (int64_t)i[1] + dy, (int64_t)i[2] + dz };
+            int64_t p[3] = { c[0], c[1], c[2] }, m[3] = { c[0], c[1], c[2] };
+            int64_t lim = axis == 0 ? X : axis == 1 ? Y : Z;
+            p[axis] = c[axis] + 1 < lim - 1 ? c[axis] + 1 : lim - 1;
+            m[axis] = c[axis] - 1 > 0 ? c[axis] - 1 : 0;
+            d[dz][dy][dx] = buf[p[0] + p[1] * X + p[2] * X * Y] - buf[m[0] + m[1] * X + m[2] * X * Y];
+        }
+        g[axis] = lerpf(lerpf(lerpf(d[0][0][0], d[0][0][1], f[0]), lerpf(d[0][1][0], d[0][1][1], f[0]), f[1]),
+                        lerpf(lerpf(d[1][0][0], d[1][0][1], f[0]), lerpf(d[1][1][0], d[1][1][1], f[0]), f[1]), f[2]);
+    }
+}
+
+/* sampleLabel, brats_rt.slang:78-83 */
+static inline uint32_t sample_label(const uint32_t* buf, const float* q, const uint32_t* dims) {
+    uint32_t i[3];
+    for (int k = 0; k < 3; ++k) i[k] = (uint32_t)roundf(clampf(q[k], 0.0f, (float)dims[k] - 1.0f));
+    return buf[i[0] + (size_t)i[1] * dims[0] + (size_t)i[2] * dims[0] * dims[1]];
+}
+
+/* K1 for rows [row0,row1); out is the FULL image (pitch = width pixels), fp32 RGBA.
+ * stats (optional, 2 x uint64): live samples, shaded samples. */
+int oracle_brats_main(const OracleBratsParams* P, const float* const vols[4], const uint32_t* labels,
+                      const uint32_t* preds, float* out, uint32_t row0, uint32_t row1, uint64_t* stats) {
+    const uint32_t Wd = P->width, Hd = P->height;
+    if (row1 > Hd) row1 = Hd;
+    float bmin[3], bmax[3];
+    for (int k = 0; k < 3; ++k) { bmin[k] = P->volMin[k]; bmax[k] = P->volMin[k] + P->voxelSize[k] * (float)P->dims[k]; }
+    uint64_t live = 0, shaded = 0;
+    const float ert = P->ertThreshold;
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : live, shaded)
+    for (uint32_t py = row0; py < row1; ++py) {
+        for (uint32_t px = 0; px < Wd; ++px) {
+            float* o4 = out + ((size_t)py * Wd + px) * 4;
+            float ro[3], rd[3];
+            if (P->cameraMode == 0) {
+                memcpy(ro, P->eye, sizeof ro);
+                make_primary(px, py, Wd, Hd, P->fovY, 0, P->U, P->V, P->W, rd);
+            } else {
+                float dimx = (float)Wd, dimy = (float)Hd;
+                float uvx = (((float)px + 0.5f) / dimx) * 2.0f - 1.0f;
+                float uvy = (((float)py + 0.5f) / dimy) * 2.0f - 1.0f;
+                float aspect = dimx / fmaxf(1.0f, dimy);
+                float sx = uvx * P->orthoHalfHeight * aspect, sy = -uvy * P->orthoHalfHeight;
+                for (int k = 0; k < 3; ++k) { ro[k] = (P->eye[k] + P->U[k] * sx) + P->V[k] * sy; rd[k] = P->W[k]; }
+            }
+            float tmin = -INFINITY, tmax = INFINITY;
+            for (int k = 0; k < 3; ++k) {
+                float d = fabsf(rd[k]) < 1e-6f ? 1e-6f : rd[k];
+                float rcp = 1.0f / d;
+                float a = (bmin[k] - ro[k]) * rcp, b = (bmax[k] - ro[k]) * rcp;
+                tmin = fmaxf(tmin, fminf(a, b));
+                tmax = fminf(tmax, fmaxf(a, b));
+            }
+            o4[0] = P->bgColor[0]; o4[1] = P->bgColor[1]; o4[2] = P->bgColor[2]; o4[3] = 1.0f;
+            if (!(tmax >= fmaxf(tmin, 0.0f))) continue;
+            float t0 = fmaxf(tmin, fmaxf(0.0f, P->nearT));
+            float t1 = fminf(tmax, P->farT > 0.0f ? P->farT : tmax);
+            if (t1 <= t0) continue;
+            float C[3] = { P->bgColor[0], P->bgColor[1], P->bgColor[2] };
+            float T = 1.0f, t = t0;
+            while (t < t1 && T > ert) {
+                float q[3];
+                for (int k = 0; k < 3; ++k) {
+                    float p = ro[k] + t * rd[k];
+                    q[k] = (p - bmin[k]) / P->voxelSize[k];
+                }
+                float v = 0.0f, wSum = 0.0f, g[3] = { 0.0f, 0.0f, 0.0f };
+                for (int m = 0; m < 4; ++m) {
+                    if (P->volEnabled[m] != 0) {
+                        uint32_t i[3]; float f[3];
+                        v += sample_linear(vols[m], q, P->dims, i, f) * P->volWeight[m];
+                        wSum += P->volWeight[m];
+                        if (P->shadeMode != 0) {
+                            float gm[3];
+                            lattice_gradient(vols[m], i, f, P->dims, gm);
+                            for (int k = 0; k < 3; ++k) g[k] += gm[k] * P->volWeight[m];
+                        }
+                    }
+                }
+                if (wSum > 0.0f) {
+                    v /= wSum;
+                    if (P->shadeMode != 0) for (int k = 0; k < 3; ++k) g[k] /= wSum;
+                }
+                float val = satf((v - (P->wl - P->ww * 0.5f)) / P->ww);
+                val = powf_cr(val, P->gamma);
+                ++live;
+                if (val > 0.0f) {
+                    float a = val * P->intensityAlpha;
+                    float alpha = 1.0f - expf_cr(-a * P->stepSize);
+                    float emis = val;
+                    if (P->shadeMode != 0) {
+                        float gw[3];
+                        for (int k = 0; k < 3; ++k) gw[k] = (g[k] * 0.5f) / P->voxelSize[k];
+                        float glen = sqrtf(dot3(gw, gw));
+                        float shade;
+                        if (glen > P->gradEps) {
+                            float nrm[3] = { gw[0] / glen, gw[1] / glen, gw[2] / glen };
+                            float ndl = fminf(fabsf(dot3(nrm, rd)), 1.0f);
+                            float spec = ndl;
+                            for (uint32_t s = 0; s < P->specPow2; ++s) spec = spec * spec;
+                            shade = (P->ka + P->kd * ndl) + P->ks * spec;
+                        } else {
+                            shade = P->ka + P->kd;
+                        }
+                        emis = val * shade;
+                        ++shaded;
+                    }
+                    float c = (alpha * T) * emis;
+                    C[0] += c; C[1] += c; C[2] += c;
+                    T *= (1.0f - alpha);
+                }
+                if (P->showSeg != 0) {
+                    uint32_t l = sample_label(labels, q, P->dims);
+                    if (l > 0 && l < 8) {
+                        const float* col = P->lut[l];
+                        float alpha = 1.0f - expf_cr(-col[3] * P->stepSize);
+                        float at = alpha * T;
+                        C[0] += at * col[0]; C[1] += at * col[1]; C[2] += at * col[2];
+                        T *= (1.0f - alpha);
+                    }
+                }
+                if (P->showPred != 0) {
+                    uint32_t l = sample_label(preds, q, P->dims);
+                    if (l > 0 && l < 8) {
+                        const float* col = P->lut[l];
+                        float alpha = 1.0f - expf_cr(-col[3] * P->stepSize * 1.5f);
+                        float at = alpha * T;
+                        C[0] += at * col[0]; C[1] += at * col[1]; C[2] += at * col[2];
+                        T *= (1.0f - alpha);
+                    }
+                }
+                t += P->stepSize;
+            }
+            o4[0] = C[0]; o4[1] = C[1]; o4[2] = C[2];
+        }
+    }
+    if (stats) { stats[0] = live; stats[1] = shaded; }
+    return 0;
+}
+
+static inline float fetch_k2(const void* vol, size_t idx, uint32_t mode) {
+    if (mode == 0) return (float)(((const uint32_t*)vol)[idx] & 0xffu) / 255.0f;   /* volume_render.slang:33-38 */
+    if (mode == 1) return (float)((const uint8_t*)vol)[idx] / 255.0f;
+    return ((const float*)vol)[idx];
+}
+
+/* K2: volume_render.slang:104-148.  stats (optional, 1 x uint64): fetched samples. */
+int oracle_volume_cs(const OracleVolumeParams* P, const void* vol, float* out,
+                     uint32_t row0, uint32_t row1, uint64_t* stats) {
+    const uint32_t Wd = P->width, Hd = P->height;
+    if (row1 > Hd) row1 = Hd;
+    const uint32_t* d = P->volDim;
+    uint64_t live = 0;
+    const float th = tanf_cr(0.5f * P->fovY);
+    const float steps = fmaxf(1.0f, P->stepCount);
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : live)
+    for (uint32_t py = row0; py < row1; ++py) {
+        for (uint32_t px = 0; px < Wd; ++px) {
+            float invx = 1.0f / (float)Wd, invy = 1.0f / (float)Hd;
+            float uvx = ((float)px + 0.5f) * invx, uvy = ((float)py + 0.5f) * invy;
+            float ndcx = uvx * 2.0f - 1.0f, ndcy = 1.0f - uvy * 2.0f;
+            float aspect = (float)Wd / fmaxf(1.0f, (float)Hd);
+            float n = fmaxf(0.0f, P->nearPlane), f = fmaxf(n, P->farPlane);
+            float wn[3], wf[3], sv[3], pos[3];
+            if (P->cameraMode == 0) {
+                float vx = ndcx * aspect * th, vy = ndcy * th, vz = 1.0f;
+                for (int k = 0; k < 3; ++k) {
+                    wn[k] = ((P->eye[k] + P->U[k] * (vx * n)) + P->V[k] * (vy * n)) + P->W[k] * (vz * n);
+                    wf[k] = ((P->eye[k] + P->U[k] * (vx * f)) + P->V[k] * (vy * f)) + P->W[k] * (vz * f);
+                }
+            } else {
+                float sx = ndcx * aspect * P->orthoHalfHeight, sy = ndcy * P->orthoHalfHeight;
+                for (int k = 0; k < 3; ++k) {
+                    wn[k] = ((P->eye[k] + P->U[k] * sx) + P->V[k] * sy) + P->W[k] * n;
+                    wf[k] = ((P->eye[k] + P->U[k] * sx) + P->V[k] * sy) + P->W[k] * f;
+                }
+            }
+            for (int k = 0; k < 3; ++k) { sv[k] = (wf[k] - wn[k]) / steps; pos[k] = wn[k]; }
+            float accum = 0.0f;
+            const float scale = 4.0f / steps;
+            for (uint32_t i = 0; i < (uint32_t)steps; ++i) {
+                int inside = pos[0] < 1.0f && pos[1] < 1.0f && pos[2] < 1.0f &&
+                             pos[0] > -1.0f && pos[1] > -1.0f && pos[2] > -1.0f;
+                if (inside && accum < 1.0f) {
+                    float x[3], t[3]; uint32_t p0[3], p1[3];
+                    for (int k = 0; k < 3; ++k) {
+                        x[k] = satf(0.5f * (pos[k] + 1.0f)) * ((float)d[k] - 1.0f);
+                        float fl = floorf(x[k]);
+                        p0[k] = (uint32_t)fl;
+                        p1[k] = p0[k] + 1 < d[k] - 1 ? p0[k] + 1 : d[k] - 1;
+                        t[k] = x[k] - (float)p0[k];
+                    }
+                    size_t sY = d[0], sZ = (size_t)d[0] * d[1];
+#define AT(ix, iy, iz) fetch_k2(vol, (ix) + (iy) * sY + (iz) * sZ, P->mode)
+                    float c000 = AT(p0[0], p0[1], p0[2]), c100 = AT(p1[0], p0[1], p0[2]);
+                    float c010 = AT(p0[0], p1[1], p0[2]), c110 = AT(p1[0], p1[1], p0[2]);
+                    float c001 = AT(p0[0], p0[1], p1[2]), c101 = AT(p1[0], p0[1], p1[2]);
+                    float c011 = AT(p0[0], p1[1], p1[2]), c111 = AT(p1[0], p1[1], p1[2]);
+#undef AT
+                    float c00 = lerpf(c000, c100, t[0]), c01 = lerpf(c001, c101, t[0]);
+                    float c10 = lerpf(c010, c110, t[0]), c11 = lerpf(c011, c111, t[0]);
+                    float c0 = lerpf(c00, c10, t[1]), c1 = lerpf(c01, c11, t[1]);
+                    float s = lerpf(c0, c1, t[2]) * scale;
+                    accum += (1.0f - accum) * s;
+                    ++live;
+                }
+                pos[0] += sv[0]; pos[1] += sv[1]; pos[2] += sv[2];
+                if (accum > 0.995f) break;
+            }
+            float* o4 = out + ((size_t)py * Wd + px) * 4;
+            o4[0] = accum; o4[1] = accum; o4[2] = accum; o4[3] = 1.0f;
+        }
+    }
+    if (stats) stats[0] = live;
+    return 0;
+}
+
+/* K3: raymarch.slang:60-99 */
+int oracle_raymarch_cs(const OracleSdfParams* P, float* out) {
+    const uint32_t Wd = P->width, Hd = P->height;
+#pragma omp parallel for schedule(dynamic, 4)
+    for (uint32_t py = 0; py < Hd; ++py) {
+        for (uint32_t px = 0; px < Wd; ++px) {
+            float rd[3];
+            make_primary(px, py, Wd, Hd, P->fovY, 1, P->U, P->V, P->W, rd);
+            float t = 0.0f, p[3] = { P->eye[0], P->eye[1], P->eye[2] };
+            int hit = 0;
+            for (uint32_t i = 0; i < P->maxSteps; ++i) {
+                for (int k = 0; k < 3; ++k) p[k] = P->eye[k] + t * rd[k];
+                float d = sqrtf(dot3(p, p)) - 0.6f;
+                if (d < P->hitThreshold) { hit = 1; break; }
+                t += clampf(d, 0.01f, 0.25f);
+                if (t > P->maxDistance) break;
+            }
+            float* o4 = out + ((size_t)py * Wd + px) * 4;
+            if (hit) {
+                float nrm[3] = { p[0], p[1], p[2] };
+                normalize3(nrm);
+                float u = (float)atan2((double)nrm[2], (double)nrm[0]) / (2.0f * 3.14159265f) + 0.5f;
+                float v = nrm[1] * 0.5f + 0.5f;
+                o4[0] = u; o4[1] = v; o4[2] = 1.0f - u;
+            } else {
+                float dn[3] = { rd[0], rd[1], rd[2] };
+                normalize3(dn);
+                float tbg = 0.5f * (dn[1] + 1.0f);
+                o4[0] = lerpf(0.05f, 0.2f, tbg); o4[1] = lerpf(0.06f, 0.25f, tbg); o4[2] = lerpf(0.08f, 0.3f, tbg);
+            }
+            o4[3] = 1.0f;
+        }
+    }
+    return 0;
+}
+
+uint32_t oracle_struct_sizes(uint32_t which) {
+    return which == 0 ? (uint32_t)sizeof(OracleBratsParams)
+         : which == 1 ? (uint32_t)sizeof(OracleVolumeParams) : (uint32_t)sizeof(OracleSdfParams);
+}

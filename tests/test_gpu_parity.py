@@ -1,0 +1,301 @@
+"""HIP-vs-oracle parity on a real MI355X, through the C ABI (libmrirt.so via ctypes).
+
+Bars (BASELINE.json: images within 1e-4 max-abs of the CPU reference, fp32):
+  * STRICT math: the kernels evaluate the oracle's unfused fp32 expression tree with fp64-backed
+    exp, so the images are compared at 1e-6 max-abs and the live-sample counts must be equal.
+  * FAST math (FMA + hardware exp2/rcp): 1e-4 max-abs over robust pixels; pixels the oracle
+    flags as knife-edge for early termination (T within 1e-5 of 0.01, t within 4 ulp of t1) are
+    counted, must be rare, and are bounded by the analytic flip error ert*max(val, lut.rgb).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+STRICT_TOL = 1e-6
+FAST_TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    import mrirt
+    from mrirt import synth
+    from oracle import oracle_c, oracle_np
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
+    mrirt._lib.lib()          # raises if libmrirt.so is missing: no fallback
+    return dict(torch=torch, mrirt=mrirt, synth=synth, oc=oracle_c, onp=oracle_np)
+
+
+@pytest.fixture(scope="module")
+def scene48(env):
+    synth = env["synth"]
+    dims = (48, 40, 36)
+    vols = [synth.synth_volume(0, 1234 + m, phase=0.3 * m, dims=dims) for m in range(4)]
+    lab = synth.synth_labels(0, dims=dims)
+    prd = np.roll(lab, 7).copy()
+    return dims, vols, lab, prd
+
+
+K1_CASES = {
+    "viewer_default_4ch_seg": (dict(channels=4, show_seg=True), None),
+    "one_channel": (dict(channels=1), None),
+    "dense_seg_pred": (dict(channels=2, show_seg=True, show_pred=True, intensity_alpha=16.0), None),
+    "shade_dense": (dict(channels=1, intensity_alpha=16.0), "SHADE"),
+    "shade_3ch_ortho": (dict(channels=3, intensity_alpha=4.0), "SHADE_ORTHO"),
+}
+
+
+def _ext(env, tag):
+    synth = env["synth"]
+    if tag is None:
+        return None
+    if tag == "SHADE":
+        return dict(synth.SHADE_EXT)
+    return dict(synth.SHADE_EXT, cameraMode=1, orthoHalfHeight=1.1)
+
+
+def _oracle_ext(ext):
+    keys = ("cameraMode", "orthoHalfHeight", "shadeMode", "ka", "kd", "ks", "specPow2", "gradEps", "ertThreshold")
+    return {k: v for k, v in (ext or {}).items() if k in keys and v is not None}
+
+
+@pytest.mark.parametrize("case", sorted(K1_CASES))
+@pytest.mark.parametrize("layout", ["linear", "brick"])
+def test_k1_strict_matches_oracle(env, scene48, case, layout):
+    mrirt, synth, oc = env["mrirt"], env["synth"], env["oc"]
+    dims, vols, lab, prd = scene48
+    kw, tag = K1_CASES[case]
+    ext = _ext(env, tag)
+    p = synth.brats_scene(0, 0, 96, dims=dims, image_hw=(72, 88), **kw)
+    ref, aux = oc.brats_main(p, vols, lab, prd, _oracle_ext(ext), return_aux=True)
+    g = [mrirt.upload_grid(v, dims, layout) for v in vols]
+    gl, gp = mrirt.upload_grid(lab, dims, layout), mrirt.upload_grid(prd, dims, layout)
+    img, st = mrirt.render_brats(p, g, gl, gp, ext=dict(ext or {}, math="strict"), stats=True)
+    got = img.cpu().numpy()
+    assert got.shape == ref.shape and got.dtype == np.float32
+    err = np.abs(got - ref).max()
+    assert err <= STRICT_TOL, f"{case}/{layout}: max-abs {err:.3e}"
+    assert st["live_samples"] == aux["live_samples"]
+    assert st["shaded_samples"] == aux["shaded_samples"]
+    assert np.all(got[..., 3] == 1.0)
+
+
+@pytest.mark.parametrize("case", sorted(K1_CASES))
+def test_k1_fast_within_tolerance(env, scene48, case):
+    mrirt, synth, onp = env["mrirt"], env["synth"], env["onp"]
+    dims, vols, lab, prd = scene48
+    kw, tag = K1_CASES[case]
+    ext = _ext(env, tag)
+    p = synth.brats_scene(0, 0, 96, dims=dims, image_hw=(72, 88), **kw)
+    ref, aux = onp.brats_main(p, vols, lab, prd, _oracle_ext(ext), return_aux=True)
+    g = [mrirt.upload_grid(v, dims, "brick") for v in vols]
+    gl, gp = mrirt.upload_grid(lab, dims, "brick"), mrirt.upload_grid(prd, dims, "brick")
+    got = mrirt.render_brats(p, g, gl, gp, ext=dict(ext or {}, math="fast")).cpu().numpy()
+    diff = np.abs(got - ref)[..., :3].max(axis=-1)
+    robust = ~aux["fragile"]
+    assert diff[robust].max() <= FAST_TOL, f"{case}: robust max-abs {diff[robust].max():.3e}"
+    assert aux["fragile"].mean() < 0.01
+    # knife-edge pixels: one step more or less changes C by at most T*alpha*emission <= 0.01
+    assert diff.max() <= 0.01 + FAST_TOL
+
+
+def test_k1_plain_abi_entry(env, scene48):
+    """mrirt_render_brats (no ext): the reference's layout and behaviour, raw pointers."""
+    import ctypes as C
+    torch, mrirt, synth, oc = env["torch"], env["mrirt"], env["synth"], env["oc"]
+    from mrirt import _lib
+    from mrirt.params import brats_params
+    dims, vols, lab, prd = scene48
+    p = synth.brats_scene(0, 0, 64, dims=dims, image_hw=(50, 70), channels=4, show_seg=True)
+    ref = oc.brats_main(p, vols, lab, prd)
+    dv = [torch.from_numpy(v).cuda() for v in vols]
+    dl = torch.from_numpy(lab.view(np.int32)).cuda()
+    out = torch.full((50, 80, 4), -1.0, device="cuda")      # pitch 80 > width 70
+    P = brats_params(p)
+    vp = (C.c_void_p * 4)(*[C.c_void_p(t.data_ptr()) for t in dv])
+    rc = _lib.lib().mrirt_render_brats(C.byref(P), vp, C.c_void_p(dl.data_ptr()), None, C.c_void_p(out.data_ptr()),
+                                       80, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    got = out.cpu().numpy()
+    assert np.abs(got[:, :70] - ref).max() <= STRICT_TOL
+    assert np.all(got[:, 70:] == -1.0), "pixels beyond imageSize must not be written"
+
+
+def test_k1_error_codes(env, scene48):
+    mrirt, synth = env["mrirt"], env["synth"]
+    dims, vols, lab, prd = scene48
+    p = synth.brats_scene(0, 0, 64, dims=dims, image_hw=(32, 32), channels=1)
+    with pytest.raises(ValueError):
+        mrirt.render_brats(p, [vols[0][:100]])                      # too small
+    bad = dict(p, dims=np.array([1, 40, 36], np.uint32))
+    with pytest.raises(Exception):
+        mrirt.render_brats(bad, [vols[0]])
+    with pytest.raises(KeyError):
+        mrirt.render_brats({k: v for k, v in p.items() if k != "ww"}, [vols[0]])
+
+
+def test_k1_half_output_and_ert_override(env, scene48):
+    mrirt, synth, oc = env["mrirt"], env["synth"], env["oc"]
+    dims, vols, lab, prd = scene48
+    p = synth.brats_scene(0, 0, 96, dims=dims, image_hw=(40, 56), channels=1, intensity_alpha=16.0)
+    ref = oc.brats_main(p, vols, None, None)
+    h = mrirt.render_brats(p, [vols[0]], ext=dict(outFormat="rgba16f")).cpu().numpy()
+    assert h.dtype == np.float16
+    assert np.array_equal(h, ref.astype(np.float16))
+    # ERT off (threshold 0): semantics differ from the reference by design, oracle agrees
+    ref0 = oc.brats_main(p, vols, None, None, dict(ertThreshold=0.0))
+    got0 = mrirt.render_brats(p, [vols[0]], ext=dict(ertThreshold=0.0)).cpu().numpy()
+    assert np.abs(got0 - ref0).max() <= STRICT_TOL
+    assert np.abs(ref0 - ref).max() > 1e-4          # the 0.01 cut-off is part of the semantics
+
+
+def test_brick_roundtrip(env):
+    torch, mrirt = env["torch"], env["mrirt"]
+    rng = np.random.default_rng(5)
+    for dims in ((8, 8, 4), (9, 7, 5), (33, 18, 3), (64, 64, 64)):
+        for dt in (np.float32, np.uint8, np.int32):
+            a = (rng.random(dims[0] * dims[1] * dims[2]) * 200).astype(dt)
+            g = mrirt.upload_grid(a, dims, "brick")
+            assert g.data.numel() == mrirt.render.brick_elems(dims)
+            back = mrirt.unbrick_grid(g).cpu().numpy()
+            assert np.array_equal(back, a), (dims, dt)
+    # layout definition: voxel (x,y,z) sits at brick (x>>2,y>>2,z>>1), offset (x&3)+4(y&3)+16(z&1)
+    dims = (9, 7, 5)
+    a = np.arange(9 * 7 * 5, dtype=np.float32)
+    b = mrirt.upload_grid(a, dims, "brick").data.cpu().numpy()
+    nbx, nby = 3, 2
+    for (x, y, z) in ((0, 0, 0), (8, 6, 4), (5, 3, 2), (4, 4, 1)):
+        off = ((z >> 1) * nby + (y >> 2)) * nbx * 32 + (x >> 2) * 32 + (x & 3) + 4 * (y & 3) + 16 * (z & 1)
+        assert b[off] == a[x + y * 9 + z * 63]
+
+
+@pytest.mark.parametrize("mode", ["u32x4", "u8", "f32"])
+def test_k2_matches_oracle(env, mode):
+    mrirt, synth, oc, onp = env["mrirt"], env["synth"], env["oc"], env["onp"]
+    dims = (40, 36, 30)
+    f = synth.synth_volume(0, 1234, dims=dims)
+    u8 = np.rint(f * 255).astype(np.uint8)
+    vol = {"u32x4": onp.pack_u8_volume(u8), "u8": u8, "f32": f}[mode]
+    for steps, near, far in ((64, 1.5, 4.5), (33, 2.6, 2.9), (16, 0.0, 9.0)):
+        p = synth.volume_scene(0, 0, steps, near, far, dims=dims)
+        p["imageSize"] = (np.uint32(76), np.uint32(52))
+        ref, aux = oc.volume_cs(p, vol, mode=mode, return_aux=True)
+        img, st = mrirt.render_volume_u8(p, vol, mode=mode, stats=True)
+        got = img.cpu().numpy()
+        assert np.array_equal(got, ref), f"{mode} steps {steps}: max-abs {np.abs(got - ref).max():.3e}"
+        assert st["live_samples"] == aux["live_samples"]
+        fast = mrirt.render_volume_u8(p, vol, mode=mode, ext=dict(math="fast")).cpu().numpy()
+        assert np.abs(fast - ref).max() <= FAST_TOL + 0.005 * (ref.max() > 0.995)   # accum>0.995 break flips
+
+
+def test_k2_ortho_f32_config1(env):
+    """BASELINE config 1 at reduced size: K2 loop on an fp32 grid, orthographic segments."""
+    mrirt, synth, oc = env["mrirt"], env["synth"], env["oc"]
+    f = synth.synth_volume(32, 1234)
+    p = synth.volume_scene(32, 64, 64)
+    ext = dict(cameraMode=1, orthoHalfHeight=1.1)
+    ref = oc.volume_cs(p, f, mode="f32", ext=ext)
+    got = mrirt.render_volume_u8(p, f, mode="f32", ext=ext).cpu().numpy()
+    assert np.array_equal(got, ref)
+
+
+def test_k3_matches_oracle(env):
+    mrirt, synth, oc = env["mrirt"], env["synth"], env["oc"]
+    sp, eye, U, V, W = synth.sdf_scene()
+    for (w, h) in ((64, 48), (80, 80), (33, 17)):
+        ref = oc.raymarch_cs(sp, eye, U, V, W, w, h)
+        got = mrirt.render_sdf(sp, eye, U, V, W, w, h).cpu().numpy()
+        # hit colour goes through atan2 (fp64 on both sides); everything else is unfused fp32
+        assert np.abs(got - ref).max() <= STRICT_TOL
+
+
+def test_tiles_compact_and_detile(env, scene48):
+    """Tile sharding on ONE device: N ranks' compact buffers, stacked, de-tile to the full frame."""
+    torch, mrirt, synth = env["torch"], env["mrirt"], env["synth"]
+    from mrirt import tiles
+    dims, vols, lab, prd = scene48
+    p = synth.brats_scene(0, 0, 64, dims=dims, image_hw=(100, 150), channels=1, intensity_alpha=16.0)
+    g = [mrirt.upload_grid(vols[0], dims, "brick")]
+    full = mrirt.render_brats(p, g).cpu().numpy()
+    for world in (2, 3, 8):
+        parts = []
+        max_local = tiles.local_tile_count(150, 100, 32, 0, world)
+        for r in range(world):
+            t = mrirt.render_brats(p, g, ext=tiles.shard_ext(None, r, world, 32))
+            assert t.shape[0] == tiles.local_tile_count(150, 100, 32, r, world)
+            if t.shape[0] < max_local:
+                t = torch.cat([t, t.new_zeros((max_local - t.shape[0],) + tuple(t.shape[1:]))])
+            parts.append(t)
+        frame = tiles.assemble_frame(torch.stack(parts), 150, 100, 32, world).cpu().numpy()
+        assert np.array_equal(frame, full), f"world {world}"
+
+
+def test_shim_dispatch_like_the_viewer(env, scene48):
+    """The reference's call shape: create_buffer/copy_from_numpy, create_texture(rgba16_float),
+    kernel.dispatch(thread_count, vars={... gParams dict ...}, command_encoder)."""
+    mrirt, synth, oc = env["mrirt"], env["synth"], env["oc"]
+    from mrirt import shim
+    dims, vols, lab, prd = scene48
+    dev = shim.Device(enable_debug_layers=True)
+    kernel = dev.create_compute_kernel(dev.load_program("brats_rt.slang", ["brats_main"]))
+    bufs = []
+    for v in vols:
+        b = dev.create_buffer(element_count=v.size, struct_size=4, usage=shim.BufferUsage.shader_resource)
+        b.copy_from_numpy(v)
+        bufs.append(b)
+    seg = dev.create_buffer(element_count=lab.size, struct_size=4)
+    seg.copy_from_numpy(lab)
+    empty_u = dev.create_buffer(element_count=1, struct_size=4)
+    empty_u.copy_from_numpy(np.zeros(1, np.uint32))
+    tex = dev.create_texture(format=shim.Format.rgba16_float, width=96, height=64,
+                             usage=shim.TextureUsage.shader_resource | shim.TextureUsage.unordered_access)
+    p = synth.brats_scene(0, 0, 96, dims=dims, image_hw=(64, 96), channels=4, show_seg=True)
+    ce = dev.create_command_encoder()
+    kernel.dispatch(thread_count=[96, 64, 1],
+                    vars={"gOutput": tex, "gIntensity0": bufs[0], "gIntensity1": bufs[1], "gIntensity2": bufs[2],
+                          "gIntensity3": bufs[3], "gLabels": seg, "gPreds": empty_u, "gParams": p},
+                    command_encoder=ce)
+    dev.submit_command_buffer(ce.finish())
+    ref = oc.brats_main(p, vols, lab, None)
+    assert np.array_equal(tex.to_numpy(), ref.astype(np.float16))
+    with pytest.raises(KeyError):
+        kernel.dispatch(thread_count=[96, 64, 1], vars={"gOutput": tex, "gParams": p}, command_encoder=ce)
+    with pytest.raises(RuntimeError):
+        dev.load_program("x.slang", ["no_such_entry"])
+
+
+def test_full_size_properties(env):
+    """BASELINE-sized run (512^3, 1024^2, 512 steps, gradient shading + ERT) checked through
+    size-independent properties, plus an oracle comparison on a band of rows."""
+    torch, mrirt, synth, oc = env["torch"], env["mrirt"], env["synth"], env["oc"]
+    n, image, steps = 512, 1024, 512
+    vol = synth.synth_volume(n)
+    p = synth.brats_scene(n, image, steps, channels=1, intensity_alpha=16.0)
+    ext = dict(synth.SHADE_EXT)
+    gl = mrirt.upload_grid(vol, (n, n, n), "linear")
+    gb = mrirt.upload_grid(vol, (n, n, n), "brick")
+    a, sa = mrirt.render_brats(p, [gl], ext=ext, stats=True)
+    b, sb = mrirt.render_brats(p, [gb], ext=ext, stats=True)
+    assert torch.equal(a, b), "layout must not change a single bit"
+    assert sa == sb and 0 < sa["live_samples"] < image * image * steps
+    img = b.cpu().numpy()
+    assert np.isfinite(img).all() and img[..., :3].min() >= 0.0 and np.all(img[..., 3] == 1.0)
+    assert np.array_equal(img[..., 0], img[..., 1]) and np.array_equal(img[..., 0], img[..., 2])   # grey emission
+    # idempotence / determinism
+    assert torch.equal(b, mrirt.render_brats(p, [gb], ext=ext))
+    # tile-sharded rendering reproduces the frame bit for bit
+    from mrirt import tiles
+    parts = [mrirt.render_brats(p, [gb], ext=tiles.shard_ext(ext, r, 4, 64)) for r in range(4)]
+    assert torch.equal(tiles.assemble_frame(torch.stack(parts), image, image, 64, 4), b)
+    # oracle on a 16-row band through the middle of the image (seconds of CPU time)
+    rows = (504, 520)
+    ref, aux = oc.brats_main(p, [vol], None, None, synth.SHADE_EXT, return_aux=True, rows=rows)
+    assert np.abs(img[rows[0]:rows[1]] - ref).max() <= STRICT_TOL
+    # ERT really fires in this configuration, and linearity in bgColor holds:
+    # C(bg) = C(0) + bg exactly where no sample contributes; elsewhere C >= bg
+    p2 = dict(p, bgColor=np.array([0.25, 0.25, 0.25], np.float32))
+    c2 = mrirt.render_brats(p2, [gb], ext=ext).cpu().numpy()
+    miss = img[..., 0] == 0.0
+    assert np.all(c2[..., 0][miss] == 0.25)
