@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--image", type=int, default=0, help="image side; 0 = 1024*sqrt(gpus) rounded to the tile")
     ap.add_argument("--march-steps", type=int, default=512)
     ap.add_argument("--math", default="strict", choices=["strict", "fast"])
-    ap.add_argument("--layout", default="brick", choices=["brick", "linear"])
+    ap.add_argument("--layout", default="brick", choices=["vg", "quad", "brick", "linear"])
     ap.add_argument("--no-shade", action="store_true", help="reference-only K1 (no gradient shading)")
     ap.add_argument("--alpha", type=float, default=16.0, help="intensityAlpha (16 = dense preset: ERT fires)")
     ap.add_argument("--variant", type=int, default=0, help="kernelVariant (experiments)")

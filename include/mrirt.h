@@ -62,7 +62,19 @@ typedef struct MrirtBratsParams {
 /* Grid storage layouts.  LINEAR is the reference's (x fastest: x + y*X + z*X*Y,
  * inr/viewer/brats_viewer.py:64).  BRICK is this library's HBM layout (DESIGN.md "Data
  * layout"): 4x4x2-voxel bricks, one 128-byte line per fp32 brick, produced by mrirt_brick_*. */
-typedef enum MrirtLayout { MRIRT_LAYOUT_LINEAR = 0, MRIRT_LAYOUT_BRICK = 1 } MrirtLayout;
+typedef enum MrirtLayout {
+    MRIRT_LAYOUT_LINEAR = 0,
+    MRIRT_LAYOUT_BRICK = 1,
+    /* fp32 intensity grids only: one float4 per voxel, 2x2x2-voxel bricks (8 x 16 B = one 128-B
+     * line).  VG   = (v, dv/dx, dv/dy, dv/dz) with the lattice central differences
+     *                v[clamp(c+e)] - v[clamp(c-e)] precomputed at load time (mrirt_build_vg_grid):
+     *                a gradient-shaded sample is 8 dwordx4 gathers instead of 32 dword gathers,
+     *                bit-identical arithmetic.
+     *        QUAD = (v[x,y], v[x+1,y], v[x,y+1], v[x+1,y+1]) (indices clamped): an unshaded
+     *                trilinear sample is 2 dwordx4 gathers instead of 8 dword gathers.          */
+    MRIRT_LAYOUT_VG = 2,
+    MRIRT_LAYOUT_QUAD = 3
+} MrirtLayout;
 
 typedef enum MrirtMath {
     MRIRT_MATH_STRICT = 0,  /* unfused fp32 in the oracle's order, fp64-backed exp/pow: bit-faithful */
@@ -84,14 +96,15 @@ typedef struct MrirtRenderExt {
     float    ertThreshold;
     uint32_t math;              /* MrirtMath                                                   */
     uint32_t outFormat;         /* MrirtOutFormat                                              */
-    uint32_t layout;            /* MrirtLayout of ALL bound fp32 grids and label grids         */
+    uint32_t layout;            /* MrirtLayout of ALL bound fp32 intensity grids               */
+    uint32_t labelLayout;       /* MrirtLayout (LINEAR or BRICK) of the labels / preds grids   */
     /* Image-tile sharding (one process per GPU).  tileWorld <= 1: whole image into
      * out[y*pitch + x].  Otherwise this call renders the tiles t with t % tileWorld ==
      * tileRank (t = ty*tilesX + tx, tiles of tileSize^2 pixels) into a COMPACT buffer
      * out[local_tile][tileSize][tileSize][4]; pitch is ignored.                            */
     uint32_t tileSize, tileRank, tileWorld;
     uint32_t kernelVariant;     /* 0 = library default; others select experimental kernels (bench/tests) */
-    uint32_t reserved[3];
+    uint32_t reserved[2];
 } MrirtRenderExt;
 
 /* Drop-in for kernel.dispatch(...) of brats_main, inr/viewer/brats_viewer.py:431-442.
@@ -122,6 +135,10 @@ int64_t mrirt_brick_elems(const uint32_t dims[3]);
 int mrirt_brick_grid(const void* linear, void* bricked, const uint32_t dims[3], uint32_t elem_bytes, void* stream);
 /* inverse, for round-trip tests */
 int mrirt_unbrick_grid(const void* bricked, void* linear, const uint32_t dims[3], uint32_t elem_bytes, void* stream);
+/* Number of float4 ELEMENTS a VG / QUAD grid of `dims` occupies. */
+int64_t mrirt_vec4_elems(const uint32_t dims[3]);
+/* linear fp32 (x fastest) -> VG or QUAD float4 grid (layout = MRIRT_LAYOUT_VG / _QUAD). */
+int mrirt_build_vec4_grid(const float* linear, void* vec4_grid, const uint32_t dims[3], uint32_t layout, void* stream);
 
 /* ------------------------------------------------------------------------------------ */
 /* K2  volume_cs                                                                         */

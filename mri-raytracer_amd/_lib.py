@@ -21,14 +21,14 @@ HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-s
 # every extern "C" symbol include/mrirt.h declares
 ABI_SYMBOLS = [
     "mrirt_render_brats", "mrirt_render_brats_ex", "mrirt_brick_elems", "mrirt_brick_grid",
-    "mrirt_unbrick_grid", "mrirt_render_volume", "mrirt_render_sdf", "mrirt_tiles_for_rank",
+    "mrirt_unbrick_grid", "mrirt_vec4_elems", "mrirt_build_vec4_grid", "mrirt_render_volume", "mrirt_render_sdf", "mrirt_tiles_for_rank",
     "mrirt_detile", "mrirt_inr_pack_bytes", "mrirt_inr_pack_weights", "mrirt_inr_forward",
     "mrirt_inr_predict_volume", "mrirt_abi_version", "mrirt_status_string", "mrirt_last_hip_error",
     "mrirt_sizeof",
 ]
 
 OK = 0
-LAYOUT_LINEAR, LAYOUT_BRICK = 0, 1
+LAYOUT_LINEAR, LAYOUT_BRICK, LAYOUT_VG, LAYOUT_QUAD = 0, 1, 2, 3
 MATH_STRICT, MATH_FAST = 0, 1
 OUT_RGBA32F, OUT_RGBA16F = 0, 1
 VOX_U32X4, VOX_U8, VOX_F32 = 0, 1, 2
@@ -59,9 +59,9 @@ class RenderExt(C.Structure):
         ("cameraMode", u32), ("orthoHalfHeight", f32),
         ("shadeMode", u32), ("ka", f32), ("kd", f32), ("ks", f32), ("specPow2", u32), ("gradEps", f32),
         ("ertOverride", u32), ("ertThreshold", f32),
-        ("math", u32), ("outFormat", u32), ("layout", u32),
+        ("math", u32), ("outFormat", u32), ("layout", u32), ("labelLayout", u32),
         ("tileSize", u32), ("tileRank", u32), ("tileWorld", u32),
-        ("kernelVariant", u32), ("reserved", u32 * 3),
+        ("kernelVariant", u32), ("reserved", u32 * 2),
     ]
 
 
@@ -148,6 +148,9 @@ def lib() -> C.CDLL:
     l.mrirt_brick_elems.restype = i64
     l.mrirt_brick_grid.argtypes = [vp, vp, C.POINTER(u32), u32, vp]
     l.mrirt_unbrick_grid.argtypes = [vp, vp, C.POINTER(u32), u32, vp]
+    l.mrirt_vec4_elems.argtypes = [C.POINTER(u32)]
+    l.mrirt_vec4_elems.restype = i64
+    l.mrirt_build_vec4_grid.argtypes = [vp, vp, C.POINTER(u32), u32, vp]
     l.mrirt_render_volume.argtypes = [C.POINTER(VolumeParams), C.POINTER(RenderExt), vp, u32, vp, i64, vp, vp]
     l.mrirt_render_sdf.argtypes = [C.POINTER(SdfParams), u32, u32, vp, i64, vp]
     l.mrirt_tiles_for_rank.argtypes = [u32, u32, u32, u32, u32]
@@ -162,7 +165,7 @@ def lib() -> C.CDLL:
     l.mrirt_status_string.restype = C.c_char_p
     l.mrirt_sizeof.argtypes = [u32]
     l.mrirt_sizeof.restype = u32
-    for fn in ("mrirt_render_brats", "mrirt_render_brats_ex", "mrirt_brick_grid", "mrirt_unbrick_grid",
+    for fn in ("mrirt_render_brats", "mrirt_render_brats_ex", "mrirt_brick_grid", "mrirt_unbrick_grid", "mrirt_build_vec4_grid",
                "mrirt_render_volume", "mrirt_render_sdf", "mrirt_detile", "mrirt_inr_pack_weights",
                "mrirt_inr_forward", "mrirt_inr_predict_volume", "mrirt_abi_version", "mrirt_last_hip_error"):
         getattr(l, fn).restype = i32

@@ -2,14 +2,22 @@
 // shader `brats_main` (reference: inr/viewer/brats_rt.slang:85-168; helpers :36-83).
 //
 // One lane = one ray; one wave64 = an 8x8 pixel packet (the reference's numthreads(8,8,1)
-// group), one 256-thread workgroup = 2x2 packets.  The march loop is a plain divergent loop:
-// the wave's EXEC mask IS the ballot of live rays, and the backend leaves the loop with
-// s_cbranch_execz when the last lane of the packet has terminated (t >= t1 or T <= 0.01), so
-// every lane stops accumulating exactly where the scalar shader does.
+// group).  The march loop is a divergent loop: the wave's EXEC mask IS the ballot of live rays,
+// and the wave leaves the loop (s_cbranch_execz) when its last lane has terminated (t >= t1 or
+// T <= 0.01), so every lane stops accumulating exactly where the scalar shader does.
 //
-// Template axes: STRICT (bit-faithful unfused fp32 / FAST FMA + hardware exp2), LAYOUT (the
-// reference's linear grid / 4x4x2 bricks), SHADE (lattice-gradient Blinn-Phong extension),
-// HALF (rgba16_float output like the reference's texture).
+// What bounds it (profiles/r01_*): not HBM bytes.  With dword gathers it was the vector L1's tag
+// rate (~36 line accesses per wave-level gather); with one 16-byte gather per corner it is the
+// serial chain  gather -> trilerp -> exp -> T test -> next gather.  Hence
+//   * layouts where every gather brings 16 useful bytes from a 128-B 2x2x2-voxel brick
+//     (VG = value + lattice gradient, QUAD = the four xy neighbours);
+//   * a software-pipelined loop (march_pipe_kernel): the gathers of step k+1 are issued before
+//     step k is composited.  They are speculative only in that the ray may end at step k; the
+//     addresses are clamped into the grid, so the extra fetch is harmless;
+//   * one packet per workgroup (64 threads), so a finished packet's wave slot refills at once.
+//
+// Template axes: STRICT (bit-faithful to the oracle / FAST: FMA + hardware exp2, rcp), LAYOUT
+// (0 linear, 1 4x4x2 fp32 bricks, 2 VG, 3 QUAD), SHADE (lattice-gradient Blinn-Phong extension).
 #include "mrirt_host.h"
 
 namespace mrirt {
@@ -18,7 +26,12 @@ struct K1Args {
     Camera cam;
     PixelMap map;
     GridDims grid;
-    float bmin[3], bmax[3], voxelSize[3], invVoxel[3];
+    LabelAddr lab;
+    float bmin[3], bmax[3];
+    UDiv vox[3];             // voxelSize per axis (pIdx = (p - bmin) / voxelSize)
+    UDiv wsum;               // sum of the enabled volWeight, accumulated in slot order
+    UDiv wwDiv;              // ww
+    float halfInvVoxel[3];   // 0.5f / voxelSize      (gradient to world units)
     float hiLin[3];          // float(dims) - 1.001f   (sampleLinear clamp)
     float hiLab[3];          // float(dims) - 1.0f     (sampleLabel clamp)
     float stepSize, nearT, farT;
@@ -26,247 +39,411 @@ struct K1Args {
     uint32_t enabled[4];
     float weight[4];
     float tfLo;              // wl - ww*0.5
-    float ww, intensityAlpha, gamma;
+    float intensityAlpha, gamma;
     uint32_t showSeg, showPred;
     float lut[8][4];
     float ka, kd, ks, gradEps, ert;
     uint32_t specPow2;
-    const float* vol[4];
+    uint32_t half;           // 1: rgba16_float output
+    uint32_t soleChannel;    // index of the only enabled modality (pipelined kernel)
+    const void* vol[4];
     const uint32_t* labels;
     const uint32_t* preds;
     void* out;
     uint64_t* stats;
 };
 
-template <bool STRICT, int LAYOUT, bool SHADE>
-__device__ __forceinline__ void sample_channel(const float* __restrict__ buf, const GridDims& gd,
-                                               uint32_t ix, uint32_t iy, uint32_t iz,
-                                               float fx, float fy, float fz, float& v, float g[3]) {
-    using A = Addr<LAYOUT>;
-    using Mm = M<STRICT>;
-    const uint32_t x0 = A::ox(gd, ix), x1 = A::ox(gd, ix + 1);
-    const uint32_t y0 = A::oy(gd, iy), y1 = A::oy(gd, iy + 1);
-    const uint32_t z0 = A::oz(gd, iz), z1 = A::oz(gd, iz + 1);
-    // core 2x2x2 (sampleLinear, brats_rt.slang:69-72)
-    const float c000 = buf[x0 + y0 + z0], c100 = buf[x1 + y0 + z0];
-    const float c010 = buf[x0 + y1 + z0], c110 = buf[x1 + y1 + z0];
-    const float c001 = buf[x0 + y0 + z1], c101 = buf[x1 + y0 + z1];
-    const float c011 = buf[x0 + y1 + z1], c111 = buf[x1 + y1 + z1];
-    v = Mm::lerp(Mm::lerp(Mm::lerp(c000, c100, fx), Mm::lerp(c010, c110, fx), fy),
-                 Mm::lerp(Mm::lerp(c001, c101, fx), Mm::lerp(c011, c111, fx), fy), fz);
-    if constexpr (SHADE) {
-        // 24 more voxels: the +-1 neighbours of the 8 corners along each axis (indices clamped)
-        const uint32_t xm = A::ox(gd, ix > 0 ? ix - 1 : 0), xp = A::ox(gd, min(ix + 2, gd.X - 1));
-        const uint32_t ym = A::oy(gd, iy > 0 ? iy - 1 : 0), yp = A::oy(gd, min(iy + 2, gd.Y - 1));
-        const uint32_t zm = A::oz(gd, iz > 0 ? iz - 1 : 0), zp = A::oz(gd, min(iz + 2, gd.Z - 1));
-        {   // d/dx: corner (0,dy,dz): v[i+1]-v[i-1]; corner (1,dy,dz): v[i+2]-v[i]
-            const float d000 = c100 - buf[xm + y0 + z0], d100 = buf[xp + y0 + z0] - c000;
-            const float d010 = c110 - buf[xm + y1 + z0], d110 = buf[xp + y1 + z0] - c010;
-            const float d001 = c101 - buf[xm + y0 + z1], d101 = buf[xp + y0 + z1] - c001;
-            const float d011 = c111 - buf[xm + y1 + z1], d111 = buf[xp + y1 + z1] - c011;
-            g[0] = Mm::lerp(Mm::lerp(Mm::lerp(d000, d100, fx), Mm::lerp(d010, d110, fx), fy),
-                            Mm::lerp(Mm::lerp(d001, d101, fx), Mm::lerp(d011, d111, fx), fy), fz);
-        }
-        {   // d/dy
-            const float d000 = c010 - buf[x0 + ym + z0], d100 = c110 - buf[x1 + ym + z0];
-            const float d010 = buf[x0 + yp + z0] - c000, d110 = buf[x1 + yp + z0] - c100;
-            const float d001 = c011 - buf[x0 + ym + z1], d101 = c111 - buf[x1 + ym + z1];
-            const float d011 = buf[x0 + yp + z1] - c001, d111 = buf[x1 + yp + z1] - c101;
-            g[1] = Mm::lerp(Mm::lerp(Mm::lerp(d000, d100, fx), Mm::lerp(d010, d110, fx), fy),
-                            Mm::lerp(Mm::lerp(d001, d101, fx), Mm::lerp(d011, d111, fx), fy), fz);
-        }
-        {   // d/dz
-            const float d000 = c001 - buf[x0 + y0 + zm], d100 = c101 - buf[x1 + y0 + zm];
-            const float d010 = c011 - buf[x0 + y1 + zm], d110 = c111 - buf[x1 + y1 + zm];
-            const float d001 = buf[x0 + y0 + zp] - c000, d101 = buf[x1 + y0 + zp] - c100;
-            const float d011 = buf[x0 + y1 + zp] - c010, d111 = buf[x1 + y1 + zp] - c110;
-            g[2] = Mm::lerp(Mm::lerp(Mm::lerp(d000, d100, fx), Mm::lerp(d010, d110, fx), fy),
-                            Mm::lerp(Mm::lerp(d001, d101, fx), Mm::lerp(d011, d111, fx), fy), fz);
-        }
-    }
+template <bool STRICT>
+__device__ __forceinline__ float trilerp(float c000, float c100, float c010, float c110,
+                                         float c001, float c101, float c011, float c111,
+                                         float fx, float fy, float fz) {
+    using Mm = M<STRICT>;   // nesting order of sampleLinear, brats_rt.slang:74-75
+    return Mm::lerp(Mm::lerp(Mm::lerp(c000, c100, fx), Mm::lerp(c010, c110, fx), fy),
+                    Mm::lerp(Mm::lerp(c001, c101, fx), Mm::lerp(c011, c111, fx), fy), fz);
 }
 
-template <int LAYOUT>
-__device__ __forceinline__ uint32_t sample_label(const uint32_t* __restrict__ buf, const GridDims& gd,
+// ---------------------------------------------------------------------------------------
+// One sample's position in index space: sampleLinear's clamp / floor / fract (shared by all
+// modalities) plus the unclamped pIdx the label fetch rounds.
+// ---------------------------------------------------------------------------------------
+struct Cell {
+    float q[3];              // pIdx
+    float fx, fy, fz;
+    uint32_t ix, iy, iz;
+};
+
+template <bool STRICT>
+__device__ __forceinline__ void locate(const K1Args& a, const float ro[3], const float rd[3], float t, Cell& c) {
+    using Mm = M<STRICT>;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float p = Mm::mad(t, rd[k], ro[k]);                    // o + t*d (the sum commutes)
+        c.q[k] = Mm::divu(p - a.bmin[k], a.vox[k]);                  // brats_rt.slang:119-120
+    }
+    const float cx = clampf(c.q[0], 0.0f, a.hiLin[0]);               // :62-64
+    const float cy = clampf(c.q[1], 0.0f, a.hiLin[1]);
+    const float cz = clampf(c.q[2], 0.0f, a.hiLin[2]);
+    const float flx = floorf(cx), fly = floorf(cy), flz = floorf(cz);
+    c.ix = (uint32_t)flx; c.iy = (uint32_t)fly; c.iz = (uint32_t)flz;
+    c.fx = cx - flx; c.fy = cy - fly; c.fz = cz - flz;
+}
+
+// ---------------------------------------------------------------------------------------
+// Taps: the gathers of one modality at one cell (issue), and their blend (eval).  Splitting the
+// two lets the pipelined kernel keep a whole step of gathers in flight.
+// ---------------------------------------------------------------------------------------
+template <int LAYOUT, bool SHADE> struct Taps;
+
+template <bool SHADE> struct Taps<2, SHADE> {        // VG: 8 x (v, dx, dy, dz)
+    float4 c[8];
+    __device__ __forceinline__ void issue(const void* __restrict__ vbuf, const GridDims& gd, const Cell& s) {
+        using A = Addr<2>;
+        const float4* __restrict__ b = static_cast<const float4*>(vbuf);
+        const uint32_t x0 = A::ox(gd, s.ix), x1 = A::ox(gd, s.ix + 1);
+        const uint32_t y0 = A::oy(gd, s.iy), y1 = A::oy(gd, s.iy + 1);
+        const uint32_t z0 = A::oz(gd, s.iz), z1 = A::oz(gd, s.iz + 1);
+        c[0] = b[x0 + y0 + z0]; c[1] = b[x1 + y0 + z0]; c[2] = b[x0 + y1 + z0]; c[3] = b[x1 + y1 + z0];
+        c[4] = b[x0 + y0 + z1]; c[5] = b[x1 + y0 + z1]; c[6] = b[x0 + y1 + z1]; c[7] = b[x1 + y1 + z1];
+    }
+    template <bool STRICT>
+    __device__ __forceinline__ void eval(const Cell& s, float& v, float g[3]) const {
+        v = trilerp<STRICT>(c[0].x, c[1].x, c[2].x, c[3].x, c[4].x, c[5].x, c[6].x, c[7].x, s.fx, s.fy, s.fz);
+        if constexpr (SHADE) {
+            g[0] = trilerp<STRICT>(c[0].y, c[1].y, c[2].y, c[3].y, c[4].y, c[5].y, c[6].y, c[7].y, s.fx, s.fy, s.fz);
+            g[1] = trilerp<STRICT>(c[0].z, c[1].z, c[2].z, c[3].z, c[4].z, c[5].z, c[6].z, c[7].z, s.fx, s.fy, s.fz);
+            g[2] = trilerp<STRICT>(c[0].w, c[1].w, c[2].w, c[3].w, c[4].w, c[5].w, c[6].w, c[7].w, s.fx, s.fy, s.fz);
+        }
+    }
+};
+
+template <> struct Taps<3, false> {                  // QUAD: the z and z+1 xy-quads
+    float4 q0, q1;
+    __device__ __forceinline__ void issue(const void* __restrict__ vbuf, const GridDims& gd, const Cell& s) {
+        using A = Addr<3>;
+        const float4* __restrict__ b = static_cast<const float4*>(vbuf);
+        const uint32_t xy = A::ox(gd, s.ix) + A::oy(gd, s.iy);
+        q0 = b[xy + A::oz(gd, s.iz)];
+        q1 = b[xy + A::oz(gd, s.iz + 1)];
+    }
+    template <bool STRICT>
+    __device__ __forceinline__ void eval(const Cell& s, float& v, float*) const {
+        v = trilerp<STRICT>(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, s.fx, s.fy, s.fz);
+    }
+};
+
+template <int LAYOUT, bool SHADE> struct TapsScalar {        // LINEAR / BRICK fp32 grids
+    float c[8];
+    float n[SHADE ? 24 : 1];                                 // +-1 neighbours of the 8 corners per axis
+    __device__ __forceinline__ void issue(const void* __restrict__ vbuf, const GridDims& gd, const Cell& s) {
+        using A = Addr<LAYOUT>;
+        const float* __restrict__ buf = static_cast<const float*>(vbuf);
+        const uint32_t x0 = A::ox(gd, s.ix), x1 = A::ox(gd, s.ix + 1);
+        const uint32_t y0 = A::oy(gd, s.iy), y1 = A::oy(gd, s.iy + 1);
+        const uint32_t z0 = A::oz(gd, s.iz), z1 = A::oz(gd, s.iz + 1);
+        // core 2x2x2 (sampleLinear, brats_rt.slang:69-72)
+        c[0] = buf[x0 + y0 + z0]; c[1] = buf[x1 + y0 + z0]; c[2] = buf[x0 + y1 + z0]; c[3] = buf[x1 + y1 + z0];
+        c[4] = buf[x0 + y0 + z1]; c[5] = buf[x1 + y0 + z1]; c[6] = buf[x0 + y1 + z1]; c[7] = buf[x1 + y1 + z1];
+        if constexpr (SHADE) {
+            const uint32_t xm = A::ox(gd, s.ix > 0 ? s.ix - 1 : 0), xp = A::ox(gd, min(s.ix + 2, gd.X - 1));
+            const uint32_t ym = A::oy(gd, s.iy > 0 ? s.iy - 1 : 0), yp = A::oy(gd, min(s.iy + 2, gd.Y - 1));
+            const uint32_t zm = A::oz(gd, s.iz > 0 ? s.iz - 1 : 0), zp = A::oz(gd, min(s.iz + 2, gd.Z - 1));
+            n[0] = buf[xm + y0 + z0]; n[1] = buf[xp + y0 + z0]; n[2] = buf[xm + y1 + z0]; n[3] = buf[xp + y1 + z0];
+            n[4] = buf[xm + y0 + z1]; n[5] = buf[xp + y0 + z1]; n[6] = buf[xm + y1 + z1]; n[7] = buf[xp + y1 + z1];
+            n[8] = buf[x0 + ym + z0]; n[9] = buf[x1 + ym + z0]; n[10] = buf[x0 + yp + z0]; n[11] = buf[x1 + yp + z0];
+            n[12] = buf[x0 + ym + z1]; n[13] = buf[x1 + ym + z1]; n[14] = buf[x0 + yp + z1]; n[15] = buf[x1 + yp + z1];
+            n[16] = buf[x0 + y0 + zm]; n[17] = buf[x1 + y0 + zm]; n[18] = buf[x0 + y1 + zm]; n[19] = buf[x1 + y1 + zm];
+            n[20] = buf[x0 + y0 + zp]; n[21] = buf[x1 + y0 + zp]; n[22] = buf[x0 + y1 + zp]; n[23] = buf[x1 + y1 + zp];
+        }
+    }
+    template <bool STRICT>
+    __device__ __forceinline__ void eval(const Cell& s, float& v, float g[3]) const {
+        v = trilerp<STRICT>(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], s.fx, s.fy, s.fz);
+        if constexpr (SHADE) {
+            // corner (0,dy,dz): v[i+1]-v[i-1]; corner (1,dy,dz): v[i+2]-v[i]; likewise in y and z
+            g[0] = trilerp<STRICT>(c[1] - n[0], n[1] - c[0], c[3] - n[2], n[3] - c[2],
+                                   c[5] - n[4], n[5] - c[4], c[7] - n[6], n[7] - c[6], s.fx, s.fy, s.fz);
+            g[1] = trilerp<STRICT>(c[2] - n[8], c[3] - n[9], n[10] - c[0], n[11] - c[1],
+                                   c[6] - n[12], c[7] - n[13], n[14] - c[4], n[15] - c[5], s.fx, s.fy, s.fz);
+            g[2] = trilerp<STRICT>(c[4] - n[16], c[5] - n[17], c[6] - n[18], c[7] - n[19],
+                                   n[20] - c[0], n[21] - c[1], n[22] - c[2], n[23] - c[3], s.fx, s.fy, s.fz);
+        }
+    }
+};
+template <bool SHADE> struct Taps<0, SHADE> : TapsScalar<0, SHADE> {};
+template <bool SHADE> struct Taps<1, SHADE> : TapsScalar<1, SHADE> {};
+
+__device__ __forceinline__ uint32_t sample_label(const uint32_t* __restrict__ buf, const LabelAddr& la,
                                                  const float q[3], const float hi[3]) {
-    using A = Addr<LAYOUT>;
     // sampleLabel, brats_rt.slang:78-83; roundf = half away from zero (Metal round)
     const uint32_t ix = (uint32_t)roundf(clampf(q[0], 0.0f, hi[0]));
     const uint32_t iy = (uint32_t)roundf(clampf(q[1], 0.0f, hi[1]));
     const uint32_t iz = (uint32_t)roundf(clampf(q[2], 0.0f, hi[2]));
-    return buf[A::ox(gd, ix) + A::oy(gd, iy) + A::oz(gd, iz)];
+    return buf[la.off(ix, iy, iz)];
 }
 
-template <bool STRICT, int LAYOUT, bool SHADE, bool HALF>
+// ---------------------------------------------------------------------------------------
+// Everything after the blended intensity v (and weighted gradient g) is known:
+// transfer function, emission-absorption step, label overlays.  brats_rt.slang:130-162.
+// ---------------------------------------------------------------------------------------
+struct RayState { float C0, C1, C2, T; uint32_t nLive, nShaded; };
+
+template <bool STRICT, bool SHADE>
+__device__ __forceinline__ void composite(const K1Args& a, const float rd[3], const Cell& s, float v, const float g[3],
+                                          RayState& r) {
+    using Mm = M<STRICT>;
+    // wSum (brats_rt.slang:123-130) is the same for every sample: summed on the host
+    if (a.wsum.d > 0.0f) v = Mm::divu(v, a.wsum);
+    float val = satf(Mm::divu(v - a.tfLo, a.wwDiv));                 // :132
+    val = Mm::pow(val, a.gamma);                                     // :133
+    ++r.nLive;
+    if (val > 0.0f) {
+        const float alpha = 1.0f - Mm::exp(-(val * a.intensityAlpha) * a.stepSize);
+        float emis = val;
+        if constexpr (SHADE) {
+            // headlight Blinn-Phong on the lattice gradient (build-defined extension):
+            // world gradient = index-space difference * 0.5/voxelSize; n.l = |g.d| / |g|
+            const float gx = g[0] * a.halfInvVoxel[0], gy = g[1] * a.halfInvVoxel[1], gz = g[2] * a.halfInvVoxel[2];
+            const float len2 = dot3(gx, gy, gz, gx, gy, gz);
+            const float glen = STRICT ? sqrtf(len2) : __builtin_amdgcn_sqrtf(len2);
+            float shade = a.ka + a.kd;
+            if (glen > a.gradEps) {
+                const float gd = fabsf(dot3(gx, gy, gz, rd[0], rd[1], rd[2]));
+                const float ndl = fminf(STRICT ? gd / glen : gd * __builtin_amdgcn_rcpf(glen), 1.0f);
+                float spec = ndl;
+                for (uint32_t k = 0; k < a.specPow2; ++k) spec = spec * spec;
+                shade = (a.ka + a.kd * ndl) + a.ks * spec;
+            }
+            emis = val * shade;
+            ++r.nShaded;
+        }
+        const float c = (alpha * r.T) * emis;
+        r.C0 += c; r.C1 += c; r.C2 += c;
+        r.T *= (1.0f - alpha);
+    }
+    if (a.showSeg != 0) {                                            // :143-151
+        const uint32_t l = sample_label(a.labels, a.lab, s.q, a.hiLab);
+        if (l > 0 && l < 8) {
+            const float alpha = 1.0f - Mm::exp(-a.lut[l][3] * a.stepSize);
+            const float at = alpha * r.T;
+            r.C0 += at * a.lut[l][0]; r.C1 += at * a.lut[l][1]; r.C2 += at * a.lut[l][2];
+            r.T *= (1.0f - alpha);
+        }
+    }
+    if (a.showPred != 0) {                                           // :154-162
+        const uint32_t l = sample_label(a.preds, a.lab, s.q, a.hiLab);
+        if (l > 0 && l < 8) {
+            const float alpha = 1.0f - Mm::exp(-a.lut[l][3] * a.stepSize * 1.5f);
+            const float at = alpha * r.T;
+            r.C0 += at * a.lut[l][0]; r.C1 += at * a.lut[l][1]; r.C2 += at * a.lut[l][2];
+            r.T *= (1.0f - alpha);
+        }
+    }
+}
+
+// ray generation + slab clip (brats_rt.slang:91-109); returns whether the ray marches
+__device__ __forceinline__ bool setup_ray(const K1Args& a, uint32_t px, uint32_t py, float ro[3], float rd[3],
+                                          float& t0, float& t1) {
+    primary_ray(a.cam, px, py, ro, rd);
+    float tmin = -INFINITY, tmax = INFINITY;   // rcp uses the nudged direction, marching the true one
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float d = fabsf(rd[k]) < 1e-6f ? 1e-6f : rd[k];
+        const float rcp = 1.0f / d;
+        const float ta = (a.bmin[k] - ro[k]) * rcp, tb = (a.bmax[k] - ro[k]) * rcp;
+        tmin = fmaxf(tmin, fminf(ta, tb));
+        tmax = fminf(tmax, fmaxf(ta, tb));
+    }
+    const bool hit = tmax >= fmaxf(tmin, 0.0f);
+    t0 = fmaxf(tmin, fmaxf(0.0f, a.nearT));
+    t1 = fminf(tmax, a.farT > 0.0f ? a.farT : tmax);
+    return hit && !(t1 <= t0);
+}
+
+__device__ __forceinline__ void finish(const K1Args& a, int kind, int64_t oidx, const RayState& r) {
+    if (kind != 0) {
+        if (a.half) store_rgba<true>(a.out, oidx, r.C0, r.C1, r.C2, 1.0f);
+        else        store_rgba<false>(a.out, oidx, r.C0, r.C1, r.C2, 1.0f);
+    }
+    if (a.stats != nullptr) {
+        wave_count_add(a.stats + 0, r.nLive);
+        wave_count_add(a.stats + 1, r.nShaded);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// General kernel: any subset of the four modalities, gathers issued and consumed per step.
+// ---------------------------------------------------------------------------------------
+template <bool STRICT, int LAYOUT, bool SHADE>
 __global__ __launch_bounds__(256) void brats_march_kernel(const K1Args a) {
     using Mm = M<STRICT>;
     uint32_t px, py;
     int64_t oidx;
     const int kind = map_pixel(a.map, px, py, oidx);
-    if (a.map.numBlocks == 0) return;
-
-    float C0 = a.bg[0], C1 = a.bg[1], C2 = a.bg[2];
-    uint32_t nLive = 0, nShaded = 0;
-
+    RayState r = { a.bg[0], a.bg[1], a.bg[2], 1.0f, 0u, 0u };
     if (kind == 1) {
-        float ro[3], rd[3];
-        primary_ray(a.cam, px, py, ro, rd);
-        // slab test, brats_rt.slang:95-102 (rcp uses the nudged direction, marching the true one)
-        float tmin = -INFINITY, tmax = INFINITY;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const float d = fabsf(rd[k]) < 1e-6f ? 1e-6f : rd[k];
-            const float rcp = 1.0f / d;
-            const float t0 = (a.bmin[k] - ro[k]) * rcp, t1 = (a.bmax[k] - ro[k]) * rcp;
-            tmin = fmaxf(tmin, fminf(t0, t1));
-            tmax = fminf(tmax, fmaxf(t0, t1));
-        }
-        const bool hit = tmax >= fmaxf(tmin, 0.0f);
-        const float t0 = fmaxf(tmin, fmaxf(0.0f, a.nearT));
-        const float t1 = fminf(tmax, a.farT > 0.0f ? a.farT : tmax);
-        if (hit && !(t1 <= t0)) {
-            float T = 1.0f, t = t0;
-            while (t < t1 && T > a.ert) {
-                float q[3];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const float p = Mm::mad(t, rd[k], ro[k]);            // o + t*d (sum is commutative)
-                    q[k] = STRICT ? (p - a.bmin[k]) / a.voxelSize[k] : (p - a.bmin[k]) * a.invVoxel[k];
-                }
-                // sampleLinear's clamp/floor/fract is identical for all four modalities
-                const float cx = clampf(q[0], 0.0f, a.hiLin[0]);
-                const float cy = clampf(q[1], 0.0f, a.hiLin[1]);
-                const float cz = clampf(q[2], 0.0f, a.hiLin[2]);
-                const float flx = floorf(cx), fly = floorf(cy), flz = floorf(cz);
-                const uint32_t ix = (uint32_t)flx, iy = (uint32_t)fly, iz = (uint32_t)flz;
-                const float fx = cx - flx, fy = cy - fly, fz = cz - flz;
-
-                float v = 0.0f, wSum = 0.0f, g[3] = { 0.0f, 0.0f, 0.0f };
+        float ro[3], rd[3], t0, t1;
+        if (setup_ray(a, px, py, ro, rd, t0, t1)) {
+            float t = t0;
+            while (t < t1 && r.T > a.ert) {
+                Cell s;
+                locate<STRICT>(a, ro, rd, t, s);
+                float v = 0.0f, g[3] = { 0.0f, 0.0f, 0.0f };
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
                     if (a.enabled[m] != 0) {
-                        float s, gm[3];
-                        sample_channel<STRICT, LAYOUT, SHADE>(a.vol[m], a.grid, ix, iy, iz, fx, fy, fz, s, gm);
-                        v = Mm::mad(s, a.weight[m], v);
-                        wSum += a.weight[m];
+                        Taps<LAYOUT, SHADE> taps;
+                        float sv, gm[3];
+                        taps.issue(a.vol[m], a.grid, s);
+                        taps.template eval<STRICT>(s, sv, gm);
+                        v = Mm::mad(sv, a.weight[m], v);
                         if constexpr (SHADE) {
 #pragma unroll
                             for (int k = 0; k < 3; ++k) g[k] = Mm::mad(gm[k], a.weight[m], g[k]);
                         }
                     }
                 }
-                if (wSum > 0.0f) {
-                    v = v / wSum;
-                    if constexpr (SHADE) { g[0] = g[0] / wSum; g[1] = g[1] / wSum; g[2] = g[2] / wSum; }
-                }
-                // transfer function, brats_rt.slang:132-133
-                float val = satf(Mm::div(v - a.tfLo, a.ww));
-                val = Mm::pow(val, a.gamma);
-                ++nLive;
-                if (val > 0.0f) {
-                    const float alpha = 1.0f - Mm::exp(-(val * a.intensityAlpha) * a.stepSize);
-                    float emis = val;
-                    if constexpr (SHADE) {
-                        const float gx = STRICT ? (g[0] * 0.5f) / a.voxelSize[0] : (g[0] * 0.5f) * a.invVoxel[0];
-                        const float gy = STRICT ? (g[1] * 0.5f) / a.voxelSize[1] : (g[1] * 0.5f) * a.invVoxel[1];
-                        const float gz = STRICT ? (g[2] * 0.5f) / a.voxelSize[2] : (g[2] * 0.5f) * a.invVoxel[2];
-                        const float glen = sqrtf(dot3(gx, gy, gz, gx, gy, gz));
-                        float shade = a.ka + a.kd;
-                        if (glen > a.gradEps) {
-                            const float ndl = fminf(fabsf(dot3(gx / glen, gy / glen, gz / glen, rd[0], rd[1], rd[2])), 1.0f);
-                            float spec = ndl;
-                            for (uint32_t s = 0; s < a.specPow2; ++s) spec = spec * spec;
-                            shade = (a.ka + a.kd * ndl) + a.ks * spec;
-                        }
-                        emis = val * shade;
-                        ++nShaded;
-                    }
-                    const float c = (alpha * T) * emis;
-                    C0 += c; C1 += c; C2 += c;
-                    T *= (1.0f - alpha);
-                }
-                if (a.showSeg != 0) {                                  // brats_rt.slang:143-151
-                    const uint32_t l = sample_label<LAYOUT>(a.labels, a.grid, q, a.hiLab);
-                    if (l > 0 && l < 8) {
-                        const float alpha = 1.0f - Mm::exp(-a.lut[l][3] * a.stepSize);
-                        const float at = alpha * T;
-                        C0 += at * a.lut[l][0]; C1 += at * a.lut[l][1]; C2 += at * a.lut[l][2];
-                        T *= (1.0f - alpha);
-                    }
-                }
-                if (a.showPred != 0) {                                 // brats_rt.slang:154-162
-                    const uint32_t l = sample_label<LAYOUT>(a.preds, a.grid, q, a.hiLab);
-                    if (l > 0 && l < 8) {
-                        const float alpha = 1.0f - Mm::exp(-a.lut[l][3] * a.stepSize * 1.5f);
-                        const float at = alpha * T;
-                        C0 += at * a.lut[l][0]; C1 += at * a.lut[l][1]; C2 += at * a.lut[l][2];
-                        T *= (1.0f - alpha);
-                    }
-                }
+                composite<STRICT, SHADE>(a, rd, s, v, g, r);
                 t += a.stepSize;
             }
         }
     }
-    if (kind != 0) store_rgba<HALF>(a.out, oidx, C0, C1, C2, 1.0f);
-    if (a.stats != nullptr) {
-        wave_count_add(a.stats + 0, nLive);
-        wave_count_add(a.stats + 1, nShaded);
+    finish(a, kind, oidx, r);
+}
+
+// ---------------------------------------------------------------------------------------
+// Pipelined kernel: exactly one enabled modality.  Two stages ping-pong so that while stage A is
+// blended and composited, stage B's gathers (the NEXT step) are already in flight; the compiler
+// then waits with vmcnt(#gathers of one stage) instead of vmcnt(0).
+// ---------------------------------------------------------------------------------------
+template <bool STRICT, int LAYOUT, bool SHADE>
+__global__ __launch_bounds__(256) void brats_march_pipe_kernel(const K1Args a) {
+    using Mm = M<STRICT>;
+    uint32_t px, py;
+    int64_t oidx;
+    const int kind = map_pixel(a.map, px, py, oidx);
+    RayState r = { a.bg[0], a.bg[1], a.bg[2], 1.0f, 0u, 0u };
+    if (kind == 1) {
+        float ro[3], rd[3], t0, t1;
+        if (setup_ray(a, px, py, ro, rd, t0, t1) && t0 < t1 && 1.0f > a.ert) {   // the while-condition at entry
+            const void* __restrict__ vol = a.vol[a.soleChannel];
+            const float w = a.weight[a.soleChannel];
+            float t = t0;
+            Cell sA, sB;
+            Taps<LAYOUT, SHADE> A, B;
+            locate<STRICT>(a, ro, rd, t, sA);
+            A.issue(vol, a.grid, sA);
+            while (true) {
+                // invariant: stage A holds the sample at t, and (t < t1 && T > ert) holds
+                float tn = t + a.stepSize;
+                locate<STRICT>(a, ro, rd, tn, sB);
+                B.issue(vol, a.grid, sB);                             // speculative next step
+                {
+                    float sv, gm[3], g[3] = { 0.0f, 0.0f, 0.0f };
+                    A.template eval<STRICT>(sA, sv, gm);
+                    const float v = Mm::mad(sv, w, 0.0f);
+                    if constexpr (SHADE) { g[0] = Mm::mad(gm[0], w, 0.0f); g[1] = Mm::mad(gm[1], w, 0.0f); g[2] = Mm::mad(gm[2], w, 0.0f); }
+                    composite<STRICT, SHADE>(a, rd, sA, v, g, r);
+                }
+                t = tn;
+                if (!(t < t1 && r.T > a.ert)) break;
+                tn = t + a.stepSize;
+                locate<STRICT>(a, ro, rd, tn, sA);
+                A.issue(vol, a.grid, sA);
+                {
+                    float sv, gm[3], g[3] = { 0.0f, 0.0f, 0.0f };
+                    B.template eval<STRICT>(sB, sv, gm);
+                    const float v = Mm::mad(sv, w, 0.0f);
+                    if constexpr (SHADE) { g[0] = Mm::mad(gm[0], w, 0.0f); g[1] = Mm::mad(gm[1], w, 0.0f); g[2] = Mm::mad(gm[2], w, 0.0f); }
+                    composite<STRICT, SHADE>(a, rd, sB, v, g, r);
+                }
+                t = tn;
+                if (!(t < t1 && r.T > a.ert)) break;
+            }
+        }
     }
+    finish(a, kind, oidx, r);
 }
 
 template <bool STRICT, int LAYOUT, bool SHADE>
-static int launch_half(const K1Args& a, bool half, hipStream_t s) {
-    const dim3 grid(a.map.chunk * kXcds), block(256);
-    if (half) hipLaunchKernelGGL((brats_march_kernel<STRICT, LAYOUT, SHADE, true>), grid, block, 0, s, a);
-    else      hipLaunchKernelGGL((brats_march_kernel<STRICT, LAYOUT, SHADE, false>), grid, block, 0, s, a);
+static int launch(const K1Args& a, bool pipe, hipStream_t s) {
+    const dim3 grid(a.map.chunk * kXcds), block(a.map.blockPx == 8 ? 64 : 256);
+    if constexpr (LAYOUT >= 2) {
+        if (pipe) {
+            hipLaunchKernelGGL((brats_march_pipe_kernel<STRICT, LAYOUT, SHADE>), grid, block, 0, s, a);
+            MRIRT_HIP(hipGetLastError());
+            return MRIRT_OK;
+        }
+    }
+    hipLaunchKernelGGL((brats_march_kernel<STRICT, LAYOUT, SHADE>), grid, block, 0, s, a);
     MRIRT_HIP(hipGetLastError());
     return MRIRT_OK;
 }
 
-template <bool STRICT, int LAYOUT>
-static int launch_shade(const K1Args& a, bool shade, bool half, hipStream_t s) {
-    return shade ? launch_half<STRICT, LAYOUT, true>(a, half, s) : launch_half<STRICT, LAYOUT, false>(a, half, s);
+template <bool STRICT>
+static int launch_layout(const K1Args& a, uint32_t layout, bool shade, bool pipe, hipStream_t s) {
+    switch (layout) {
+        case MRIRT_LAYOUT_LINEAR: return shade ? launch<STRICT, 0, true>(a, false, s) : launch<STRICT, 0, false>(a, false, s);
+        case MRIRT_LAYOUT_BRICK:  return shade ? launch<STRICT, 1, true>(a, false, s) : launch<STRICT, 1, false>(a, false, s);
+        case MRIRT_LAYOUT_VG:     return shade ? launch<STRICT, 2, true>(a, pipe, s) : launch<STRICT, 2, false>(a, pipe, s);
+        case MRIRT_LAYOUT_QUAD:   return shade ? (int)MRIRT_ERR_LAYOUT : launch<STRICT, 3, false>(a, pipe, s);
+        default: return MRIRT_ERR_LAYOUT;
+    }
 }
 
 }  // namespace mrirt
 
 using namespace mrirt;
 
+// kernelVariant toggles (experiments; 0 = library default):
+//   bit 0: row-major instead of Morton lane order      bit 1: 256-thread instead of 64-thread workgroups
+//   bit 2: no software pipelining
 extern "C" int mrirt_render_brats_ex(const MrirtBratsParams* p, const MrirtRenderExt* ext,
                                      const void* const vol[4], const void* labels, const void* preds,
                                      void* out_rgba, int64_t pitch_px, uint64_t* stats_dev, void* stream) {
     if (!p || !out_rgba || !vol) return MRIRT_ERR_NULL;
     for (int k = 0; k < 3; ++k) if (p->dims[k] < 2) return MRIRT_ERR_DIMS;
     const uint32_t layout = ext ? ext->layout : (uint32_t)MRIRT_LAYOUT_LINEAR;
+    const uint32_t labLayout = ext ? ext->labelLayout : (uint32_t)MRIRT_LAYOUT_LINEAR;
     const uint32_t math = ext ? ext->math : (uint32_t)MRIRT_MATH_STRICT;
     const uint32_t fmt = ext ? ext->outFormat : (uint32_t)MRIRT_OUT_RGBA32F;
-    if (layout > MRIRT_LAYOUT_BRICK || math > MRIRT_MATH_FAST || fmt > MRIRT_OUT_RGBA16F) return MRIRT_ERR_LAYOUT;
-    if (mrirt_brick_elems(p->dims) >= (int64_t)1 << 32) return MRIRT_ERR_DIMS;   // 32-bit element offsets
+    const uint32_t variant = ext ? ext->kernelVariant : 0u;
+    if (layout > MRIRT_LAYOUT_QUAD || labLayout > MRIRT_LAYOUT_BRICK || math > MRIRT_MATH_FAST || fmt > MRIRT_OUT_RGBA16F)
+        return MRIRT_ERR_LAYOUT;
+    if (mrirt_brick_elems(p->dims) >= (int64_t)1 << 32 || mrirt_vec4_elems(p->dims) >= (int64_t)1 << 32)
+        return MRIRT_ERR_DIMS;                                           // 32-bit element offsets
     for (int m = 0; m < 4; ++m) if (p->volEnabled[m] != 0 && !vol[m]) return MRIRT_ERR_NULL;
     if ((p->showSeg != 0 && !labels) || (p->showPred != 0 && !preds)) return MRIRT_ERR_NULL;
 
     K1Args a;
     fill_camera(a.cam, p->eye, p->U, p->V, p->W, p->fovY, p->imageSize[0], p->imageSize[1], ext, false);
-    int rc = fill_pixel_map(a.map, p->imageSize[0], p->imageSize[1], pitch_px, ext);
+    int rc = fill_pixel_map(a.map, p->imageSize[0], p->imageSize[1], pitch_px, ext,
+                            (variant & 2u) ? 16u : 8u, (variant & 1u) ? 0u : 1u);
     if (rc != MRIRT_OK) return rc;
     fill_grid_dims(a.grid, p->dims, layout);
+    fill_label_addr(a.lab, p->dims, labLayout);
     for (int k = 0; k < 3; ++k) {
         a.bmin[k] = p->volMin[k];
         a.bmax[k] = p->volMin[k] + p->voxelSize[k] * (float)p->dims[k];
-        a.voxelSize[k] = p->voxelSize[k];
-        a.invVoxel[k] = 1.0f / p->voxelSize[k];
+        a.vox[k] = make_udiv(p->voxelSize[k]);
+        a.halfInvVoxel[k] = 0.5f / p->voxelSize[k];
         a.hiLin[k] = (float)p->dims[k] - 1.001f;
         a.hiLab[k] = (float)p->dims[k] - 1.0f;
         a.bg[k] = p->bgColor[k];
     }
     a.stepSize = p->stepSize; a.nearT = p->nearT; a.farT = p->farT;
+    float wSum = 0.0f;
+    uint32_t nEnabled = 0;
+    a.soleChannel = 0;
     for (int m = 0; m < 4; ++m) {
         a.enabled[m] = p->volEnabled[m];
         a.weight[m] = p->volWeight[m];
-        a.vol[m] = static_cast<const float*>(vol[m]);
+        a.vol[m] = vol[m];
+        if (p->volEnabled[m] != 0) { wSum += p->volWeight[m]; a.soleChannel = (uint32_t)m; ++nEnabled; }   // shader's order
     }
+    a.wsum = make_udiv(wSum);
+    a.wwDiv = make_udiv(p->ww);
     a.tfLo = p->wl - p->ww * 0.5f;
-    a.ww = p->ww; a.intensityAlpha = p->intensityAlpha; a.gamma = p->gamma;
+    a.intensityAlpha = p->intensityAlpha; a.gamma = p->gamma;
     a.showSeg = p->showSeg; a.showPred = p->showPred;
     for (int i = 0; i < 8; ++i) for (int j = 0; j < 4; ++j) a.lut[i][j] = p->lutColorAlpha[i][j];
     const bool shade = ext && ext->shadeMode != 0;
@@ -274,17 +451,17 @@ extern "C" int mrirt_render_brats_ex(const MrirtBratsParams* p, const MrirtRende
     a.gradEps = ext ? ext->gradEps : 0.0f;
     a.specPow2 = ext ? ext->specPow2 : 0u;
     a.ert = (ext && ext->ertOverride) ? ext->ertThreshold : 0.01f;   // brats_rt.slang:117
+    a.half = fmt == MRIRT_OUT_RGBA16F ? 1u : 0u;
     a.labels = static_cast<const uint32_t*>(labels);
     a.preds = static_cast<const uint32_t*>(preds);
     a.out = out_rgba;
     a.stats = stats_dev;
     if (a.map.numBlocks == 0) return MRIRT_OK;   // a rank that owns no tile
 
+    const bool pipe = nEnabled == 1 && !(variant & 4u);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const bool half = fmt == MRIRT_OUT_RGBA16F;
-    if (math == MRIRT_MATH_STRICT)
-        return layout == MRIRT_LAYOUT_LINEAR ? launch_shade<true, 0>(a, shade, half, s) : launch_shade<true, 1>(a, shade, half, s);
-    return layout == MRIRT_LAYOUT_LINEAR ? launch_shade<false, 0>(a, shade, half, s) : launch_shade<false, 1>(a, shade, half, s);
+    return math == MRIRT_MATH_STRICT ? launch_layout<true>(a, layout, shade, pipe, s)
+                                     : launch_layout<false>(a, layout, shade, pipe, s);
 }
 
 extern "C" int mrirt_render_brats(const MrirtBratsParams* params, const float* const vol[4],

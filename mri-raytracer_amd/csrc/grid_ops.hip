@@ -34,6 +34,38 @@ __global__ __launch_bounds__(256) void brick_kernel(const T* __restrict__ src, T
     }
 }
 
+// linear fp32 -> float4-per-voxel grid in 2x2x2 bricks.  One thread per (padded) voxel, in
+// destination order, so a wave writes 8 whole 128-B bricks.
+//   VG   = (v, v[x+1]-v[x-1], v[y+1]-v[y-1], v[z+1]-v[z-1]) with neighbour indices clamped to
+//          the grid — exactly the differences the gradient shader forms per corner;
+//   QUAD = (v[x,y], v[x+1,y], v[x,y+1], v[x+1,y+1]) with indices clamped.
+template <bool VG>
+__global__ __launch_bounds__(256) void vec4_build_kernel(const float* __restrict__ src, float4* __restrict__ dst,
+                                                         uint32_t X, uint32_t Y, uint32_t Z, uint32_t nbx, uint32_t nby, uint64_t total) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;      // float4 index in dst
+    if (e >= total) return;
+    const uint32_t in = (uint32_t)(e & 7u);
+    const uint64_t b = e >> 3;
+    const uint32_t bx = (uint32_t)(b % nbx), by = (uint32_t)((b / nbx) % nby), bz = (uint32_t)(b / ((uint64_t)nbx * nby));
+    const uint32_t x = bx * 2 + (in & 1u), y = by * 2 + ((in >> 1) & 1u), z = bz * 2 + (in >> 2);
+    float4 o = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (x < X && y < Y && z < Z) {
+        const uint64_t sY = X, sZ = (uint64_t)X * Y;
+        auto at = [&](uint32_t xx, uint32_t yy, uint32_t zz) { return src[xx + yy * sY + zz * sZ]; };
+        const uint32_t xp = min(x + 1, X - 1), yp = min(y + 1, Y - 1), zp = min(z + 1, Z - 1);
+        if constexpr (VG) {
+            const uint32_t xm = x > 0 ? x - 1 : 0, ym = y > 0 ? y - 1 : 0, zm = z > 0 ? z - 1 : 0;
+            o.x = at(x, y, z);
+            o.y = at(xp, y, z) - at(xm, y, z);
+            o.z = at(x, yp, z) - at(x, ym, z);
+            o.w = at(x, y, zp) - at(x, y, zm);
+        } else {
+            o = make_float4(at(x, y, z), at(xp, y, z), at(x, yp, z), at(xp, yp, z));
+        }
+    }
+    dst[e] = o;
+}
+
 template <bool HALF>
 __global__ __launch_bounds__(256) void detile_kernel(const void* __restrict__ gathered, void* __restrict__ frame,
                                                      uint32_t width, uint32_t height, int64_t pitch,
@@ -85,6 +117,28 @@ extern "C" int mrirt_brick_grid(const void* linear, void* bricked, const uint32_
 
 extern "C" int mrirt_unbrick_grid(const void* bricked, void* linear, const uint32_t dims[3], uint32_t elem_bytes, void* stream) {
     return brick_common(bricked, linear, dims, elem_bytes, false, stream);
+}
+
+extern "C" int64_t mrirt_vec4_elems(const uint32_t dims[3]) {
+    if (!dims) return 0;
+    return (int64_t)((dims[0] + 1) / 2) * ((dims[1] + 1) / 2) * ((dims[2] + 1) / 2) * 8;
+}
+
+extern "C" int mrirt_build_vec4_grid(const float* linear, void* vec4_grid, const uint32_t dims[3], uint32_t layout, void* stream) {
+    if (!linear || !vec4_grid || !dims) return MRIRT_ERR_NULL;
+    for (int k = 0; k < 3; ++k) if (dims[k] < 1) return MRIRT_ERR_DIMS;
+    if (layout != MRIRT_LAYOUT_VG && layout != MRIRT_LAYOUT_QUAD) return MRIRT_ERR_LAYOUT;
+    const uint32_t nbx = (dims[0] + 1) / 2, nby = (dims[1] + 1) / 2;
+    const uint64_t total = (uint64_t)mrirt_vec4_elems(dims);
+    if (total >= (1ull << 32)) return MRIRT_ERR_DIMS;
+    const dim3 grid((uint32_t)((total + 255) / 256)), block(256);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (layout == MRIRT_LAYOUT_VG)
+        hipLaunchKernelGGL((vec4_build_kernel<true>), grid, block, 0, s, linear, (float4*)vec4_grid, dims[0], dims[1], dims[2], nbx, nby, total);
+    else
+        hipLaunchKernelGGL((vec4_build_kernel<false>), grid, block, 0, s, linear, (float4*)vec4_grid, dims[0], dims[1], dims[2], nbx, nby, total);
+    MRIRT_HIP(hipGetLastError());
+    return MRIRT_OK;
 }
 
 extern "C" int64_t mrirt_tiles_for_rank(uint32_t width, uint32_t height, uint32_t tileSize, uint32_t rank, uint32_t world) {

@@ -18,10 +18,48 @@ constexpr int kXcds = 8;
 // ---------------------------------------------------------------------------------------
 template <bool STRICT> struct M;
 
+// A per-launch constant divisor d with its correctly rounded reciprocal r = RN(1/d) (host).
+// exact == 0 marks the one case Markstein's theorem excludes (significand of d all ones).
+struct UDiv { float d, r; uint32_t exact; };
+
+// Correctly rounded fp32 exp via fp64: 2^k * P13(x - k ln2).  Same "round a <1-ulp fp64 value
+// once" contract as (float)exp((double)x) on the host, at a third of OCML's instruction count
+// (the argument here is -(val*alpha)*dt: no need for the full double domain).
+__device__ __forceinline__ float exp_f64_to_f32(float xf) {
+    double x = fmin(fmax((double)xf, -200.0), 100.0);        // fp32 result is 0 / inf outside anyway
+    const double k = __builtin_rint(x * 1.4426950408889634);
+    double r = __builtin_fma(-k, 6.93147180369123816490e-01, x);       // ln2 hi / lo split
+    r = __builtin_fma(-k, 1.90821492927058770002e-10, r);
+    double p = 1.6059043836821613e-10;                                  // 1/13!
+    p = __builtin_fma(p, r, 2.08767569878681e-09);                      // 1/12!
+    p = __builtin_fma(p, r, 2.505210838544172e-08);                     // 1/11!
+    p = __builtin_fma(p, r, 2.755731922398589e-07);                     // 1/10!
+    p = __builtin_fma(p, r, 2.7557319223985893e-06);                    // 1/9!
+    p = __builtin_fma(p, r, 2.48015873015873e-05);                      // 1/8!
+    p = __builtin_fma(p, r, 1.984126984126984e-04);                     // 1/7!
+    p = __builtin_fma(p, r, 1.3888888888888889e-03);                    // 1/6!
+    p = __builtin_fma(p, r, 8.333333333333333e-03);                     // 1/5!
+    p = __builtin_fma(p, r, 4.1666666666666664e-02);                    // 1/4!
+    p = __builtin_fma(p, r, 1.6666666666666666e-01);                    // 1/3!
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    return (float)__builtin_ldexp(p, (int)k);
+}
+
 template <> struct M<true> {
-    // unfused, correctly rounded: mirrors oracle_c.c / oracle_np.py exactly
+    // bit-faithful to oracle_c.c / oracle_np.py: unfused fp32 in the written order; divisions
+    // and exp are correctly rounded by construction
     static __device__ __forceinline__ float lerp(float a, float b, float t) { return a + t * (b - a); }
-    static __device__ __forceinline__ float exp(float x) { return (float)::exp((double)x); }
+    static __device__ __forceinline__ float exp(float x) { return exp_f64_to_f32(x); }
+    // x / u.d, IEEE-exact in 3 instructions (Markstein: q = RN(x r); e = x - q d exactly by FMA;
+    // RN(q + e r) is the correctly rounded quotient when r = RN(1/d))
+    static __device__ __forceinline__ float divu(float x, const UDiv& u) {
+        if (!u.exact) return x / u.d;
+        const float q = x * u.r;
+        const float e = __builtin_fmaf(-q, u.d, x);
+        return __builtin_fmaf(e, u.r, q);
+    }
     static __device__ __forceinline__ float pow(float x, float y) {
         return y == 1.0f ? x : (float)::pow((double)x, (double)y);   // pow(x,1) == x exactly
     }
@@ -30,6 +68,7 @@ template <> struct M<true> {
 };
 
 template <> struct M<false> {
+    static __device__ __forceinline__ float divu(float x, const UDiv& u) { return x * u.r; }
     static __device__ __forceinline__ float lerp(float a, float b, float t) { return __builtin_fmaf(t, b - a, a); }
     static __device__ __forceinline__ float exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
     static __device__ __forceinline__ float pow(float x, float y) {
@@ -103,6 +142,26 @@ template <> struct Addr<1> {
     static __device__ __forceinline__ uint32_t oy(const GridDims& g, uint32_t y) { return (y >> 2) * g.sY + ((y & 3u) << 2); }
     static __device__ __forceinline__ uint32_t oz(const GridDims& g, uint32_t z) { return (z >> 1) * g.sZ + ((z & 1u) << 4); }
 };
+// VG / QUAD: one float4 per voxel, 2x2x2-voxel bricks (8 x 16 B = one 128-B line); offsets in
+// float4 units; sY = NBX*8, sZ = NBX*NBY*8 with NB* = ceil(dim/2).
+struct AddrVec4 {
+    static __device__ __forceinline__ uint32_t ox(const GridDims&, uint32_t x) { return ((x >> 1) << 3) + (x & 1u); }
+    static __device__ __forceinline__ uint32_t oy(const GridDims& g, uint32_t y) { return (y >> 1) * g.sY + ((y & 1u) << 1); }
+    static __device__ __forceinline__ uint32_t oz(const GridDims& g, uint32_t z) { return (z >> 1) * g.sZ + ((z & 1u) << 2); }
+};
+template <> struct Addr<2> : AddrVec4 {};
+template <> struct Addr<3> : AddrVec4 {};
+
+// Label grids (1-2 nearest fetches per sample) take their layout at run time: a separable
+// shift/mask form that covers LINEAR (shift 0, mask 0) and BRICK.
+struct LabelAddr {
+    uint32_t sh[3], mask[3], inner[3], mul[3];
+    __device__ __forceinline__ uint32_t off(uint32_t x, uint32_t y, uint32_t z) const {
+        return ((x >> sh[0]) * mul[0] + (x & mask[0]) * inner[0]) +
+               ((y >> sh[1]) * mul[1] + (y & mask[1]) * inner[1]) +
+               ((z >> sh[2]) * mul[2] + (z & mask[2]) * inner[2]);
+    }
+};
 
 // ---------------------------------------------------------------------------------------
 // workgroup -> pixel mapping, XCD-aware, with optional tile sharding
@@ -112,6 +171,8 @@ struct PixelMap {
     uint32_t blocksX, numBlocks;       // 16x16-pixel workgroups over the part of the image this call renders
     uint32_t chunk;                    // ceil(numBlocks / 8): logical ids one XCD owns
     uint32_t tileSize, tileRank, tileWorld, tilesX;   // tileWorld <= 1: whole frame
+    uint32_t laneOrder;                // 0 row-major 8x8 packet, 1 Morton (2x2 pixel quads per 4 lanes)
+    uint32_t blockPx;                  // 16: 256-thread workgroups (2x2 packets); 8: one packet per workgroup
     int64_t  pitch;                    // pixels per output row (whole-frame mode)
 };
 
@@ -125,17 +186,24 @@ __device__ __forceinline__ int map_pixel(const PixelMap& m, uint32_t& px, uint32
     uint32_t logical = (b % kXcds) * m.chunk + b / kXcds;
     if (logical >= m.numBlocks) return 0;
     uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    uint32_t lx = ((wave & 1u) << 3) + (lane & 7u), ly = ((wave >> 1) << 3) + (lane >> 3);
+    uint32_t lx, ly;
+    if (m.laneOrder == 0) {            // row-major 8x8: lane = x + 8y (the reference's thread group)
+        lx = lane & 7u; ly = lane >> 3;
+    } else {                           // Morton: every aligned group of 4 lanes is a 2x2 pixel quad
+        lx = (lane & 1u) | ((lane >> 1) & 2u) | ((lane >> 2) & 4u);
+        ly = ((lane >> 1) & 1u) | ((lane >> 2) & 2u) | ((lane >> 3) & 4u);
+    }
+    lx += (wave & 1u) << 3; ly += (wave >> 1) << 3;
     if (m.tileWorld <= 1) {
         uint32_t bx = logical % m.blocksX, by = logical / m.blocksX;
-        px = bx * kBlockPx + lx; py = by * kBlockPx + ly;
+        px = bx * m.blockPx + lx; py = by * m.blockPx + ly;
         outIndex = (int64_t)py * m.pitch + px;
     } else {
-        uint32_t bpr = m.tileSize / kBlockPx, bpt = bpr * bpr;
+        uint32_t bpr = m.tileSize / m.blockPx, bpt = bpr * bpr;
         uint32_t lt = logical / bpt, sb = logical % bpt;
         uint32_t t = m.tileRank + lt * m.tileWorld;
         uint32_t tx = t % m.tilesX, ty = t / m.tilesX;
-        uint32_t ix = (sb % bpr) * kBlockPx + lx, iy = (sb / bpr) * kBlockPx + ly;
+        uint32_t ix = (sb % bpr) * m.blockPx + lx, iy = (sb / bpr) * m.blockPx + ly;
         px = tx * m.tileSize + ix; py = ty * m.tileSize + iy;
         outIndex = ((int64_t)lt * m.tileSize + iy) * m.tileSize + ix;
         // slots of an edge tile that fall outside the image are written as background so the

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <string.h>
 
 #include "../../include/mrirt.h"
 #include "mrirt_device.h"
@@ -22,6 +23,17 @@ inline int hip_fail(hipError_t e) {
         if (e_ != hipSuccess) return ::mrirt::hip_fail(e_);     \
     } while (0)
 
+// divisor + correctly rounded reciprocal for M<STRICT>::divu (Markstein); see mrirt_device.h
+inline UDiv make_udiv(float d) {
+    UDiv u;
+    u.d = d;
+    u.r = 1.0f / d;
+    uint32_t bits;
+    memcpy(&bits, &d, sizeof bits);
+    u.exact = (isnormal(d) && isnormal(u.r) && (bits & 0x7FFFFFu) != 0x7FFFFFu) ? 1u : 0u;
+    return u;
+}
+
 // correctly rounded fp32 tan: same expression as the oracle's tanf_cr(0.5f * fovY)
 inline float tan_half_fov(float fovY) { return (float)tan((double)(0.5f * fovY)); }
 
@@ -40,22 +52,26 @@ inline void fill_camera(Camera& c, const float eye[3], const float U[3], const f
 }
 
 // returns MRIRT_OK or an error; grid size = map.chunk * 8 workgroups of 256 threads
-inline int fill_pixel_map(PixelMap& m, uint32_t width, uint32_t height, int64_t pitch, const MrirtRenderExt* ext) {
+// blockPx: 16 (256-thread workgroups) or 8 (64-thread workgroups); laneOrder: see PixelMap
+inline int fill_pixel_map(PixelMap& m, uint32_t width, uint32_t height, int64_t pitch, const MrirtRenderExt* ext,
+                          uint32_t blockPx = kBlockPx, uint32_t laneOrder = 0) {
     if (width == 0 || height == 0) return MRIRT_ERR_DIMS;
     m.width = width; m.height = height; m.pitch = pitch;
     m.tileSize = ext ? ext->tileSize : 0u;
     m.tileRank = ext ? ext->tileRank : 0u;
     m.tileWorld = ext ? ext->tileWorld : 0u;
+    m.laneOrder = laneOrder;
+    m.blockPx = blockPx;
     if (m.tileWorld <= 1) {
         if (pitch < (int64_t)width) return MRIRT_ERR_ARG;
         m.tilesX = 0;
-        m.blocksX = (width + kBlockPx - 1) / kBlockPx;
-        m.numBlocks = m.blocksX * ((height + kBlockPx - 1) / kBlockPx);
+        m.blocksX = (width + blockPx - 1) / blockPx;
+        m.numBlocks = m.blocksX * ((height + blockPx - 1) / blockPx);
     } else {
         if (m.tileSize == 0 || m.tileSize % kBlockPx != 0 || m.tileRank >= m.tileWorld) return MRIRT_ERR_ARG;
         m.tilesX = (width + m.tileSize - 1) / m.tileSize;
         int64_t local = mrirt_tiles_for_rank(width, height, m.tileSize, m.tileRank, m.tileWorld);
-        uint32_t bpr = m.tileSize / kBlockPx;
+        uint32_t bpr = m.tileSize / blockPx;
         m.blocksX = 0;
         m.numBlocks = (uint32_t)local * bpr * bpr;
     }
@@ -68,10 +84,25 @@ inline void fill_grid_dims(GridDims& g, const uint32_t dims[3], uint32_t layout)
     if (layout == MRIRT_LAYOUT_LINEAR) {
         g.sY = dims[0];
         g.sZ = dims[0] * dims[1];
+    } else if (layout == MRIRT_LAYOUT_VG || layout == MRIRT_LAYOUT_QUAD) {
+        uint32_t nbx = (dims[0] + 1) / 2, nby = (dims[1] + 1) / 2;
+        g.sY = nbx * 8;
+        g.sZ = nbx * nby * 8;
     } else {
         uint32_t nbx = (dims[0] + 3) / 4, nby = (dims[1] + 3) / 4;
         g.sY = nbx * 32;
         g.sZ = nbx * nby * 32;
+    }
+}
+
+inline void fill_label_addr(LabelAddr& a, const uint32_t dims[3], uint32_t layout) {
+    if (layout == MRIRT_LAYOUT_LINEAR) {
+        const uint32_t mul[3] = { 1u, dims[0], dims[0] * dims[1] };
+        for (int k = 0; k < 3; ++k) { a.sh[k] = 0; a.mask[k] = 0; a.inner[k] = 0; a.mul[k] = mul[k]; }
+    } else {
+        const uint32_t nbx = (dims[0] + 3) / 4, nby = (dims[1] + 3) / 4;
+        const uint32_t sh[3] = { 2, 2, 1 }, mask[3] = { 3, 3, 1 }, inner[3] = { 1, 4, 16 }, mul[3] = { 32, nbx * 32, nbx * nby * 32 };
+        for (int k = 0; k < 3; ++k) { a.sh[k] = sh[k]; a.mask[k] = mask[k]; a.inner[k] = inner[k]; a.mul[k] = mul[k]; }
     }
 }
 

@@ -19,14 +19,15 @@ EXT_DEFAULTS: Dict[str, Any] = dict(
     ertThreshold=None,            # None -> the shader's hard-coded 0.01 (brats_rt.slang:117)
     math="strict",                # "strict" (bit-faithful) | "fast"
     outFormat="rgba32f",          # "rgba32f" | "rgba16f" (the reference's texture format)
-    layout="linear",              # "linear" | "brick"
+    layout="linear",              # intensity grids: "linear" | "brick" | "vg" | "quad"
+    labelLayout="linear",         # labels / preds: "linear" | "brick"
     tileSize=0, tileRank=0, tileWorld=0,
     kernelVariant=0,
 )
 
 _MATH = {"strict": _lib.MATH_STRICT, "fast": _lib.MATH_FAST}
 _FMT = {"rgba32f": _lib.OUT_RGBA32F, "rgba16f": _lib.OUT_RGBA16F}
-_LAYOUT = {"linear": _lib.LAYOUT_LINEAR, "brick": _lib.LAYOUT_BRICK}
+_LAYOUT = {"linear": _lib.LAYOUT_LINEAR, "brick": _lib.LAYOUT_BRICK, "vg": _lib.LAYOUT_VG, "quad": _lib.LAYOUT_QUAD}
 
 _BRATS_REQUIRED = ("imageSize", "fovY", "eye", "U", "V", "W", "volMin", "voxelSize", "dims", "stepSize",
                    "nearT", "farT", "bgColor", "volEnabled", "volWeight", "ww", "wl", "intensityAlpha",
@@ -86,6 +87,7 @@ def render_ext(ext: Optional[Mapping[str, Any]] = None) -> _lib.RenderExt:
     if e["ertThreshold"] is not None:
         s.ertOverride, s.ertThreshold = 1, float(np.float32(e["ertThreshold"]))
     s.math, s.outFormat, s.layout = _MATH[e["math"]], _FMT[e["outFormat"]], _LAYOUT[e["layout"]]
+    s.labelLayout = _LAYOUT[e["labelLayout"]]
     s.tileSize, s.tileRank, s.tileWorld = int(e["tileSize"]), int(e["tileRank"]), int(e["tileWorld"])
     s.kernelVariant = int(e["kernelVariant"])
     return s

@@ -53,9 +53,16 @@ def brick_elems(dims: Sequence[int]) -> int:
     return int(_lib.lib().mrirt_brick_elems(d))
 
 
+def vec4_elems(dims: Sequence[int]) -> int:
+    d = (C.c_uint32 * 3)(*[int(v) for v in dims])
+    return int(_lib.lib().mrirt_vec4_elems(d))
+
+
 def upload_grid(linear: ArrayLike, dims: Sequence[int], layout: str = "brick", stream=None) -> Grid:
-    """Upload a linear (x-fastest) fp32 / uint32 / uint8 grid and, for ``layout='brick'``,
-    re-brick it on the device (csrc/grid_ops.hip).  Load-time, once per volume."""
+    """Upload a linear (x-fastest) fp32 / uint32 / uint8 grid and convert it on the device
+    (csrc/grid_ops.hip) to ``layout``: "linear" (as is), "brick" (4x4x2 bricks), or for fp32
+    intensities "vg" (float4 value + lattice gradient) / "quad" (float4 xy-neighbours).
+    Load-time, once per volume."""
     dev = _require_gpu()
     dims = tuple(int(v) for v in dims)
     t = torch.as_tensor(linear).reshape(-1)
@@ -69,6 +76,15 @@ def upload_grid(linear: ArrayLike, dims: Sequence[int], layout: str = "brick", s
     t = t.to(dev).contiguous()
     if layout == "linear":
         return Grid(t, dims, "linear")
+    if layout in ("vg", "quad"):
+        if t.dtype != torch.float32:
+            raise TypeError(f"layout {layout!r} is for fp32 intensity grids, got {t.dtype}")
+        out = torch.empty(4 * vec4_elems(dims), dtype=torch.float32, device=dev)
+        d = (C.c_uint32 * 3)(*dims)
+        code = _lib.LAYOUT_VG if layout == "vg" else _lib.LAYOUT_QUAD
+        _lib.check(_lib.lib().mrirt_build_vec4_grid(_ptr(t), _ptr(out), d, code, _stream_ptr(stream)),
+                   "mrirt_build_vec4_grid")
+        return Grid(out, dims, layout)
     if layout != "brick":
         raise ValueError(f"unknown layout {layout!r}")
     out = torch.empty(brick_elems(dims), dtype=t.dtype, device=dev)
@@ -142,31 +158,36 @@ def render_brats(params: Mapping[str, Any], intensities: Sequence[Optional[Union
     dev = _require_gpu()
     P = brats_params(params)
     e = dict(ext or {})
-    grids = [g for g in list(intensities) + [labels, preds] if isinstance(g, Grid)]
-    if grids and "layout" not in e:
-        e["layout"] = grids[0].layout
+    vgrids = [g for g in intensities if isinstance(g, Grid)]
+    lgrids = [g for g in (labels, preds) if isinstance(g, Grid)]
+    if vgrids and "layout" not in e:
+        e["layout"] = vgrids[0].layout
+    if lgrids and "labelLayout" not in e:
+        e["labelLayout"] = lgrids[0].layout
     E = render_ext(e)
-    lay = "brick" if E.layout == _lib.LAYOUT_BRICK else "linear"
-    for g in grids:
-        if g.layout != lay:
-            raise ValueError(f"all bound grids must share one layout ({lay}); got {g.layout}")
+    names = {v: k for k, v in (("linear", 0), ("brick", 1), ("vg", 2), ("quad", 3))}
+    lay, lab_lay = names[E.layout], names[E.labelLayout]
+    for g, want in [(g, lay) for g in vgrids] + [(g, lab_lay) for g in lgrids]:
+        if g.layout != want:
+            raise ValueError(f"bound grid is {g.layout!r} but the render call says {want!r}")
         if tuple(g.dims) != tuple(int(v) for v in P.dims):
             raise ValueError(f"grid dims {g.dims} != gParams.dims {tuple(P.dims)}")
-    nvox = int(P.dims[0]) * int(P.dims[1]) * int(P.dims[2])
-    need = brick_elems(tuple(P.dims)) if lay == "brick" else nvox
+    dims = tuple(int(v) for v in P.dims)
+    nvox = dims[0] * dims[1] * dims[2]
+    need = {"linear": nvox, "brick": brick_elems(dims), "vg": 4 * vec4_elems(dims), "quad": 4 * vec4_elems(dims)}
     vols = []
     for m in range(4):
         v = intensities[m] if m < len(intensities) else None
         t = _as_device_tensor(v, torch.float32, dev, f"gIntensity{m}")
         if P.volEnabled[m] != 0:
-            if t is None or t.numel() < need:
-                raise ValueError(f"gIntensity{m} is enabled but holds {0 if t is None else t.numel()} < {need} voxels")
+            if t is None or t.numel() < need[lay]:
+                raise ValueError(f"gIntensity{m} is enabled but holds {0 if t is None else t.numel()} < {need[lay]} elements")
         vols.append(t)
     lab = _as_device_tensor(labels, torch.int32, dev, "gLabels")
     prd = _as_device_tensor(preds, torch.int32, dev, "gPreds")
-    if P.showSeg != 0 and (lab is None or lab.numel() < need):
+    if P.showSeg != 0 and (lab is None or lab.numel() < need[lab_lay]):
         raise ValueError("showSeg is set but gLabels is missing or too small")
-    if P.showPred != 0 and (prd is None or prd.numel() < need):
+    if P.showPred != 0 and (prd is None or prd.numel() < need[lab_lay]):
         raise ValueError("showPred is set but gPreds is missing or too small")
     o, pitch = _alloc_out(int(P.imageSize[0]), int(P.imageSize[1]), E, dev, out)
     vp = (C.c_void_p * 4)(*[C.c_void_p(t.data_ptr()) if t is not None else None for t in vols])

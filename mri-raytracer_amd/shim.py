@@ -160,7 +160,7 @@ class ComputeKernel:
         # dummy 1-element buffers stand in for disabled inputs (brats_viewer.py:247-248,437-438)
         en = [int(v) != 0 for v in p["volEnabled"]] + [int(p["showSeg"]) != 0, int(p["showPred"]) != 0]
         bound = [self._buf(b, dims, layout) if on else None for b, on in zip(raw, en)]
-        e["layout"] = layout
+        e["layout"] = e["labelLayout"] = layout
         _r.render_brats(p, bound[:4], bound[4], bound[5], out=tex.tensor, ext=e)
 
     def _volume(self, tc, vars, ext):

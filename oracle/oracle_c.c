@@ -190,10 +190,7 @@ int oracle_brats_main(const OracleBratsParams* P, const float* const vols[4], co
                         }
                     }
                 }
-                if (wSum > 0.0f) {
-                    v /= wSum;
-                    if (P->shadeMode != 0) for (int k = 0; k < 3; ++k) g[k] /= wSum;
-                }
+                if (wSum > 0.0f) v /= wSum;   /* the gradient is used for its direction only */
                 float val = satf((v - (P->wl - P->ww * 0.5f)) / P->ww);
                 val = powf_cr(val, P->gamma);
                 ++live;
@@ -203,12 +200,11 @@ int oracle_brats_main(const OracleBratsParams* P, const float* const vols[4], co
                     float emis = val;
                     if (P->shadeMode != 0) {
                         float gw[3];
-                        for (int k = 0; k < 3; ++k) gw[k] = (g[k] * 0.5f) / P->voxelSize[k];
+                        for (int k = 0; k < 3; ++k) gw[k] = g[k] * (0.5f / P->voxelSize[k]);
                         float glen = sqrtf(dot3(gw, gw));
                         float shade;
                         if (glen > P->gradEps) {
-                            float nrm[3] = { gw[0] / glen, gw[1] / glen, gw[2] / glen };
-                            float ndl = fminf(fabsf(dot3(nrm, rd)), 1.0f);
+                            float ndl = fminf(fabsf(dot3(gw, rd)) / glen, 1.0f);
                             float spec = ndl;
                             for (uint32_t s = 0; s < P->specPow2; ++s) spec = spec * spec;
                             shade = (P->ka + P->kd * ndl) + P->ks * spec;

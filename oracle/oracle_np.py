@@ -320,9 +320,7 @@ def brats_main(params: Dict[str, Any], vols: Sequence[Optional[np.ndarray]],
                     for a in range(3):
                         g[a] = g[a] + gm[a] * wt[m]
         if wsum > 0:
-            v = v / wsum
-            if shade_on:
-                g = [ga / wsum for ga in g]
+            v = v / wsum          # the gradient is used for its direction only: not normalised
         val = _sat((v - (wl - ww * F(0.5))) / ww)
         val = _pow(val, gamma)
 
@@ -332,14 +330,15 @@ def brats_main(params: Dict[str, Any], vols: Sequence[Optional[np.ndarray]],
         a = val * ia
         alpha = _ONE - _exp(-a * step)
         if shade_on:
-            gx = (g[0] * F(0.5)) / vsx
-            gy = (g[1] * F(0.5)) / vsy
-            gz = (g[2] * F(0.5)) / vsz
+            # world-space gradient: index-space central difference times 0.5/voxelSize (one fp32
+            # constant per axis); headlight Blinn-Phong, two-sided: n.l = |g.d| / |g|
+            gx = g[0] * (F(0.5) / vsx)
+            gy = g[1] * (F(0.5) / vsy)
+            gz = g[2] * (F(0.5) / vsz)
             glen = np.sqrt(_dot3(gx, gy, gz, gx, gy, gz))
             ok = glen > F(e["gradEps"])
             safe = np.where(ok, glen, _ONE)
-            ndl = np.abs(_dot3(gx / safe, gy / safe, gz / safe, ddx_, ddy_, ddz_))
-            ndl = np.fmin(ndl, _ONE)
+            ndl = np.fmin(np.abs(_dot3(gx, gy, gz, ddx_, ddy_, ddz_)) / safe, _ONE)
             spec = ndl
             for _ in range(int(e["specPow2"])):
                 spec = spec * spec

@@ -62,7 +62,7 @@ def _oracle_ext(ext):
 
 
 @pytest.mark.parametrize("case", sorted(K1_CASES))
-@pytest.mark.parametrize("layout", ["linear", "brick"])
+@pytest.mark.parametrize("layout", ["linear", "brick", "vg", "quad"])
 def test_k1_strict_matches_oracle(env, scene48, case, layout):
     mrirt, synth, oc = env["mrirt"], env["synth"], env["oc"]
     dims, vols, lab, prd = scene48
@@ -71,7 +71,12 @@ def test_k1_strict_matches_oracle(env, scene48, case, layout):
     p = synth.brats_scene(0, 0, 96, dims=dims, image_hw=(72, 88), **kw)
     ref, aux = oc.brats_main(p, vols, lab, prd, _oracle_ext(ext), return_aux=True)
     g = [mrirt.upload_grid(v, dims, layout) for v in vols]
-    gl, gp = mrirt.upload_grid(lab, dims, layout), mrirt.upload_grid(prd, dims, layout)
+    lab_layout = "linear" if layout == "linear" else "brick"
+    gl, gp = mrirt.upload_grid(lab, dims, lab_layout), mrirt.upload_grid(prd, dims, lab_layout)
+    if layout == "quad" and tag is not None:
+        with pytest.raises(mrirt._lib.MrirtError):     # QUAD grids carry no gradient neighbours
+            mrirt.render_brats(p, g, gl, gp, ext=dict(ext, math="strict"))
+        return
     img, st = mrirt.render_brats(p, g, gl, gp, ext=dict(ext or {}, math="strict"), stats=True)
     got = img.cpu().numpy()
     assert got.shape == ref.shape and got.dtype == np.float32
@@ -280,6 +285,14 @@ def test_full_size_properties(env):
     b, sb = mrirt.render_brats(p, [gb], ext=ext, stats=True)
     assert torch.equal(a, b), "layout must not change a single bit"
     assert sa == sb and 0 < sa["live_samples"] < image * image * steps
+    gv = mrirt.upload_grid(vol, (n, n, n), "vg")
+    c, sc = mrirt.render_brats(p, [gv], ext=ext, stats=True)
+    assert torch.equal(a, c) and sc == sa, "value+gradient grid must not change a single bit"
+    # unshaded: QUAD and VG grids agree with the linear grid bit for bit as well
+    gq = mrirt.upload_grid(vol, (n, n, n), "quad")
+    u0 = mrirt.render_brats(p, [gl])
+    assert torch.equal(u0, mrirt.render_brats(p, [gq])) and torch.equal(u0, mrirt.render_brats(p, [gv]))
+    del gq, gv, u0, c
     img = b.cpu().numpy()
     assert np.isfinite(img).all() and img[..., :3].min() >= 0.0 and np.all(img[..., 3] == 1.0)
     assert np.array_equal(img[..., 0], img[..., 1]) and np.array_equal(img[..., 0], img[..., 2])   # grey emission
