@@ -47,7 +47,8 @@ def parse():
     ap.add_argument("--image", type=int, default=0, help="image side; 0 = 1024*sqrt(gpus) rounded to the tile")
     ap.add_argument("--march-steps", type=int, default=512)
     ap.add_argument("--math", default="strict", choices=["strict", "fast"])
-    ap.add_argument("--layout", default="brick", choices=["vg", "quad", "brick", "linear"])
+    ap.add_argument("--layout", default="auto", choices=["auto", "vg", "quad", "brick", "linear"],
+                    help="HBM layout of the volume; auto = vg (value+gradient float4 bricks) when shading, quad otherwise")
     ap.add_argument("--no-shade", action="store_true", help="reference-only K1 (no gradient shading)")
     ap.add_argument("--alpha", type=float, default=16.0, help="intensityAlpha (16 = dense preset: ERT fires)")
     ap.add_argument("--variant", type=int, default=0, help="kernelVariant (experiments)")
@@ -62,18 +63,30 @@ def cpu_baseline(params, vol, ext, rows, n_image):
     same frame.  A reported baseline, not the target."""
     from oracle import oracle_c
     oracle_c.lib()
-    r0 = max(0, n_image // 2 - rows // 2)
-    r1 = min(n_image, r0 + rows)
     okeys = ("cameraMode", "orthoHalfHeight", "shadeMode", "ka", "kd", "ks", "specPow2", "gradEps")
     oext = {k: v for k, v in ext.items() if k in okeys}
-    t = time.perf_counter()
-    _, aux = oracle_c.brats_main(params, [vol], None, None, oext, return_aux=True, rows=(r0, r1))
-    dt = time.perf_counter() - t
+
+    def run(r0, r1):
+        t = time.perf_counter()
+        _, aux = oracle_c.brats_main(params, [vol], None, None, oext, return_aux=True, rows=(r0, r1))
+        return aux["live_samples"], time.perf_counter() - t
+
+    mid = n_image // 2
+    if rows <= 0:      # calibrate on 16 central rows, then size the sample for ~12 s of wall time
+        _, dt = run(mid - 8, mid + 8)
+        rows = int(min(n_image, max(16, 16 * 12.0 / max(dt, 1e-3))))
+    r0 = max(0, mid - rows // 2)
+    r1 = min(n_image, r0 + rows)
+    reps, live, dt = 0, 0, 0.0
+    while reps < 64 and dt < 10.0:       # a many-core host finishes the whole frame in ~1 s: repeat it
+        l, d = run(r0, r1)
+        live, dt, reps = live + l, dt + d, reps + 1
+        if r1 - r0 < n_image:
+            break
     cores = int(os.environ.get("OMP_NUM_THREADS", 0)) or (os.cpu_count() or 1)
-    return {"value": round(aux["live_samples"] / dt / 1e6, 3), "unit": "Msamples/s", "cores": cores,
-            "kind": "port",
-            "sample": f"rows {r0}..{r1 - 1} of the same {n_image}x{n_image} frame "
-                      f"({aux['live_samples']} live samples, {dt:.1f} s, C/OpenMP oracle, all host threads)"}
+    return {"value": round(live / dt / 1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": f"rows {r0}..{r1 - 1} of the same {n_image}x{n_image} frame x {reps} pass(es) "
+                      f"({live} live samples in {dt:.1f} s; C/OpenMP oracle oracle/oracle_c.c, all host threads)"}
 
 
 def main():
@@ -100,6 +113,8 @@ def main():
     image = a.image or int(round(1024 * math.sqrt(world) / a.tile)) * a.tile
     vol = synth.synth_volume(n)                                   # host, deterministic
     params = synth.brats_scene(n, image, a.march_steps, channels=1, intensity_alpha=a.alpha)
+    if a.layout == "auto":
+        a.layout = "quad" if a.no_shade else "vg"
     ext = {} if a.no_shade else dict(synth.SHADE_EXT)
     ext.update(math=a.math, layout=a.layout, kernelVariant=a.variant)
     grid = mrirt.upload_grid(vol, (n, n, n), a.layout)            # resident in HBM (bricked on device)
@@ -183,8 +198,7 @@ def main():
                          "bytes_per_sample": BYTES_PER_SAMPLE + (0 if a.no_shade else BYTES_PER_SHADED)},
         }
         if not a.no_cpu_baseline and a.cpu_rows != 0 and world == 1:
-            rows = a.cpu_rows if a.cpu_rows > 0 else (192 if not a.no_shade else 512)
-            out["cpu_baseline"] = cpu_baseline(params, vol, ext, min(rows, image), image)
+            out["cpu_baseline"] = cpu_baseline(params, vol, ext, min(a.cpu_rows, image), image)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

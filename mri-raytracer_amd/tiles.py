@@ -71,9 +71,10 @@ def gather_frame(local_tiles: torch.Tensor, width: int, height: int, tile: int =
         send = torch.cat([send, pad], dim=0)
     send = send.contiguous()
     if all_ranks:
-        buf = send.new_empty((world,) + tuple(send.shape))
+        # concatenated along dim 0 (the form every backend accepts), viewed as [world, max_local, ...]
+        buf = send.new_empty((world * send.shape[0],) + tuple(send.shape[1:]))
         dist.all_gather_into_tensor(buf, send, group=group)
-        return assemble_frame(buf, width, height, tile, world)
+        return assemble_frame(buf.view((world,) + tuple(send.shape)), width, height, tile, world)
     if rank == dst:
         buf = send.new_empty((world,) + tuple(send.shape))
         dist.gather(send, list(buf.unbind(0)), dst=dst, group=group)

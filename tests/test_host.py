@@ -1,0 +1,158 @@
+"""Host-side logic, no GPU: the C-ABI library loads and exports every symbol include/mrirt.h
+declares (no compute calls), parameter marshalling, volume preparation vs the oracle, tile
+bookkeeping, and the product's refusal to run without the HIP path."""
+import ctypes as C
+import pathlib
+import re
+
+import numpy as np
+import pytest
+
+import mrirt
+from mrirt import _lib, params, synth, tiles, volume
+from oracle import oracle_np as onp
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+
+
+def test_header_symbols_are_exported():
+    hdr = (ROOT / "include" / "mrirt.h").read_text()
+    declared = set(re.findall(r"\b(mrirt_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_lib.ABI_SYMBOLS), declared ^ set(_lib.ABI_SYMBOLS)
+    lib = _lib.lib()                       # dlopen works without a GPU; no kernel is launched here
+    for s in declared:
+        assert hasattr(lib, s), s
+    assert lib.mrirt_abi_version() == 1
+    assert lib.mrirt_status_string(0) == b"ok" and b"NULL" in lib.mrirt_status_string(-1)
+
+
+def test_struct_sizes_match_the_library_and_slang_layout():
+    lib = _lib.lib()
+    for which, st in enumerate((_lib.BratsParams, _lib.RenderExt, _lib.VolumeParams, _lib.SdfParams, _lib.InrDesc)):
+        assert lib.mrirt_sizeof(which) == C.sizeof(st)
+    # struct Params of brats_rt.slang:12-31: 16-byte rows; 8 float4 LUT rows at the end
+    assert C.sizeof(_lib.BratsParams) == 16 * 15 + 16 * 8
+    assert _lib.BratsParams.lutColorAlpha.offset == 16 * 15
+    assert _lib.BratsParams.eye.offset == 16 and _lib.BratsParams.dims.offset == 16 * 7
+    assert C.sizeof(_lib.VolumeParams) == 24 + 16 * 5     # volume_render.slang:9-21
+    assert C.sizeof(_lib.RenderExt) % 4 == 0
+
+
+def test_null_and_argument_errors_without_launching():
+    lib = _lib.lib()
+    assert lib.mrirt_render_brats(None, None, None, None, None, 0, None) == -1
+    d = (C.c_uint32 * 3)(8, 8, 8)
+    assert lib.mrirt_brick_elems(d) == 2 * 2 * 4 * 32
+    assert lib.mrirt_vec4_elems(d) == 4 * 4 * 4 * 8
+    d2 = (C.c_uint32 * 3)(9, 7, 5)
+    assert lib.mrirt_brick_elems(d2) == 3 * 2 * 3 * 32 and lib.mrirt_vec4_elems(d2) == 5 * 4 * 3 * 8
+    assert lib.mrirt_brick_grid(None, None, d, 4, None) == -1
+    assert lib.mrirt_tiles_for_rank(100, 100, 64, 0, 3) == 2 and lib.mrirt_tiles_for_rank(100, 100, 64, 3, 3) == 0
+
+
+def test_brats_params_from_the_viewer_dict():
+    p = synth.brats_scene(16, 32, 64, channels=3, show_seg=True)
+    P = params.brats_params(p)
+    assert tuple(P.imageSize) == (32, 32) and tuple(P.dims) == (16, 16, 16)
+    assert list(P.volEnabled) == [1, 1, 1, 0] and P.showSeg == 1 and P.showPred == 0
+    assert np.allclose(list(P.eye), p["eye"]) and abs(P.stepSize - p["stepSize"]) < 1e-9
+    assert np.allclose(np.array([list(r) for r in P.lutColorAlpha]), synth.VIEWER_LUT)
+    assert P.gradBoost == 1.5 and P.gradScale == 1.0          # bound by the viewer, unread by the shader
+    with pytest.raises(KeyError):
+        params.brats_params({k: v for k, v in p.items() if k != "lutColorAlpha"})
+    with pytest.raises(TypeError):
+        params.brats_params(dict(p, lutColorAlpha=[(0, 0, 0, 0)] * 7))
+    E = params.render_ext(dict(synth.SHADE_EXT, math="fast", layout="vg", labelLayout="brick", ertThreshold=0.0))
+    assert (E.shadeMode, E.math, E.layout, E.labelLayout, E.ertOverride) == (1, 1, 2, 1, 1)
+    assert params.render_ext(None).ertOverride == 0
+    with pytest.raises(KeyError):
+        params.render_ext({"no_such_field": 1})
+
+
+def test_volume_prep_matches_oracle():
+    rng = np.random.default_rng(3)
+    raw = (rng.gamma(2.0, 200.0, (11, 9, 7))).astype(np.float32)
+    lin, norm, dims = volume.normalize_intensity(raw)
+    olin, onorm, odims = onp.normalize_volume(raw)
+    assert np.array_equal(lin, olin) and np.array_equal(norm, onorm) and np.array_equal(dims, odims)
+    assert lin.dtype == np.float32 and lin.min() == 0.0 and lin.max() == 1.0
+    assert lin[3 + 2 * 11 + 5 * 99] == norm[3, 2, 5]                      # x fastest
+    flat = np.full((4, 4, 4), 7.0, np.float32)                              # degenerate percentiles
+    assert np.array_equal(volume.normalize_intensity(flat)[0], onp.normalize_volume(flat)[0])
+    seg = rng.integers(0, 5, (11, 9, 7)).astype(np.float32) + rng.uniform(-0.2, 0.2, (11, 9, 7)).astype(np.float32)
+    a, ad = volume.labels_to_uint(seg)
+    b, bd = onp.flatten_labels(seg)
+    assert np.array_equal(a, b) and a.dtype == np.uint32 and np.array_equal(ad, bd)
+    for dims_, zooms in (((240, 240, 155), (1.0, 1.0, 1.0)), ((64, 128, 32), (0.5, 0.5, 2.0))):
+        got, want = volume.world_frame(dims_, zooms), onp.world_scale(dims_, zooms)
+        for g, w in zip(got, want):
+            assert np.array_equal(np.asarray(g), np.asarray(w))
+    vs, vmin, tgt, rad = volume.world_frame((240, 240, 155), (1.0, 1.0, 1.0))
+    assert abs(vs[0] * 240 - 1.8) < 1e-6 and np.allclose(tgt, 0, atol=1e-7)
+
+
+def test_u8_pack_mask_and_bc4_match_oracle():
+    rng = np.random.default_rng(4)
+    u8 = rng.integers(0, 256, 105).astype(np.uint8)
+    assert np.array_equal(volume.pack_u8_as_u32x4(u8), onp.pack_u8_volume(u8))
+    m = rng.choice([0.0, 1.0, 2.0, 4.0, 0.6], (6, 5, 4)).astype(np.float32)
+    for mode in ("occupancy", "labels"):
+        assert np.array_equal(volume.mask_to_u8(m, mode), onp.mask_to_u8(m, mode))
+    with pytest.raises(ValueError):
+        volume.mask_to_u8(m, "nope")
+    W, H, D = 10, 7, 3                                   # not multiples of 4: cropped tiles
+    blob = rng.integers(0, 256, D * 3 * 2 * 8).astype(np.uint8).tobytes()
+    assert np.array_equal(volume.bc4_decode(blob, W, H, D), onp.bc4_decode(blob, W, H, D))
+    with pytest.raises(RuntimeError):
+        volume.bc4_decode(blob[:-1], W, H, D)
+    z = rng.standard_normal((5, 4, 3)).astype(np.float32)
+    z[0, 0, 0] = 0.0
+    assert np.array_equal(volume.zscore_nonzero(z), onp.zscore_modality(z))
+
+
+def test_tile_bookkeeping():
+    for (w, h, t, world) in ((1024, 1024, 64, 8), (150, 100, 32, 3), (64, 64, 64, 4), (2880, 2880, 64, 8)):
+        n = tiles.num_tiles(w, h, t)
+        counts = [tiles.local_tile_count(w, h, t, r, world) for r in range(world)]
+        assert sum(counts) == n and max(counts) - min(counts) <= 1 and counts[0] == max(counts)
+        lib = _lib.lib()
+        assert counts == [lib.mrirt_tiles_for_rank(w, h, t, r, world) for r in range(world)]
+    assert tiles.tile_origin(5, 150, 32) == (0, 32) and tiles.tile_origin(4, 150, 32) == (128, 0)
+    e = tiles.shard_ext(dict(math="fast"), 2, 8)
+    assert e == dict(math="fast", tileSize=64, tileRank=2, tileWorld=8)
+
+
+def test_assemble_frame_on_host_tensors():
+    import torch
+    w, h, t, world = 150, 100, 32, 3
+    tx, ty = 5, 4
+    frame = torch.arange(ty * t * tx * t * 4, dtype=torch.float32).reshape(ty * t, tx * t, 4)
+    maxl = tiles.local_tile_count(w, h, t, 0, world)
+    g = torch.zeros(world, maxl, t, t, 4)
+    for tid in range(tx * ty):
+        x0, y0 = tiles.tile_origin(tid, w, t)
+        g[tid % world, tid // world] = frame[y0:y0 + t, x0:x0 + t]
+    out = tiles.assemble_frame(g, w, h, t, world)
+    assert out.shape == (h, w, 4) and torch.equal(out, frame[:h, :w])
+
+
+def test_no_cpu_fallback():
+    """Without a GPU the product must fail loudly, never route to the oracle."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    p = synth.brats_scene(8, 8, 8, channels=1)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        mrirt.render_brats(p, [np.zeros(512, np.float32)])
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        mrirt.shim.Device()
+    src = "".join(f.read_text() for f in (ROOT / "mri-raytracer_amd").glob("*.py"))
+    assert "import oracle" not in src and "from oracle" not in src
+
+
+def test_synth_is_deterministic_and_in_range():
+    a, b = synth.synth_volume(16), synth.synth_volume(16)
+    assert np.array_equal(a, b) and a.dtype == np.float32 and a.min() >= 0 and a.max() <= 1
+    lab = synth.synth_labels(16)
+    assert set(np.unique(lab)) <= {0, 1, 2, 3} and lab.dtype == np.uint32
+    assert not np.array_equal(a, synth.synth_volume(16, seed=1235))
