@@ -1,7 +1,362 @@
-// INR forward — placeholder translation unit (replaced by the MFMA kernel); entry points report
-// MRIRT_ERR_ARG so a caller fails loudly instead of reading garbage.
+// INR forward on the CDNA4 matrix cores — replaces the per-voxel MLP evaluation of the reference
+// (inr/inr/model.py:11-50 build_input + apply_mlp, :119-141 predict_volume; SIREN forward of
+// notebooks/neumors_inr.ipynb:1165-1178), which the viewer runs as a prepass over every voxel
+// (inr/viewer/brats_viewer.py:250-310).
+//
+// Formulation: every layer is computed TRANSPOSED,  Y^T[out, points] = W^T[out, in] . H^T[in, points],
+// with v_mfma_f32_32x32x16_bf16.  The 32x32 accumulator tile then has the point on the lane and the
+// output feature in the registers — exactly the B-operand shape of the next layer (k = feature), so
+// activations go  accumulator -> bias + activation -> bf16 pack -> next MFMA  without leaving the
+// register file (guide: "an accumulator tile as the next MFMA's operand").  The k order inside a
+// 16-deep step is permuted by that reuse (element j of lane half h is feature 16s + 8(j>>2) + 4h + (j&3));
+// the weights are pre-packed in the same permuted order (mrirt_inr_pack_weights), one 1-KiB fragment
+// per (out tile, k step), so an A fragment is a single coalesced 16-byte load per lane.
+//
+// Precision: bf16 operands, fp32 accumulate.  The FIRST layer sees raw coordinates and Fourier
+// features (sin(pi k c), k <= 16) and, for the SIREN, a 30x frequency scale, so its inputs and weights
+// are split hi + lo in bf16 and three products are accumulated (hi*hi + hi*lo + lo*hi: ~16 mantissa
+// bits).  Hidden layers use plain bf16.
+//
+// One wave handles PT = 2 tiles of 32 points; a workgroup is 4 waves.
 #include "mrirt_host.h"
-extern "C" int64_t mrirt_inr_pack_bytes(const MrirtInrDesc*) { return 0; }
-extern "C" int mrirt_inr_pack_weights(const MrirtInrDesc*, const float*, void*, void*) { return MRIRT_ERR_ARG; }
-extern "C" int mrirt_inr_forward(const MrirtInrDesc*, const float*, const float*, int64_t, float*, int16_t*, void*) { return MRIRT_ERR_ARG; }
-extern "C" int mrirt_inr_predict_volume(const MrirtInrDesc*, const float*, const uint32_t*, int16_t*, void*) { return MRIRT_ERR_ARG; }
+
+namespace mrirt {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kPT = 2;            // point tiles (of 32 points) per wave
+constexpr int kMaxLayers = 8;
+
+struct InrLayout {
+    uint32_t numLayers, hidden, inDim, outDim, kt0;      // kt0: 32-wide k tiles of layer 0
+    uint32_t in[kMaxLayers], out[kMaxLayers];            // true widths
+    uint32_t fragOff[kMaxLayers];                        // first fragment (1 KiB units) of each layer's image
+    uint32_t biasOff[kMaxLayers];                        // offset into the padded bias array
+    uint32_t wOff[kMaxLayers];                           // offset into the unpadded fp32 weight array
+    uint32_t totalFrags;
+};
+
+static int make_layout(const MrirtInrDesc* d, InrLayout& L) {
+    if (!d) return MRIRT_ERR_NULL;
+    if (d->numLayers < 2 || d->numLayers > kMaxLayers || d->outDim < 1 || d->outDim > 16) return MRIRT_ERR_ARG;
+    if (d->hidden != 32 && d->hidden != 64 && d->hidden != 128 && d->hidden != 256) return MRIRT_ERR_ARG;
+    if (d->inDim < 1 || d->inDim > 128 || d->kind > 3) return MRIRT_ERR_ARG;
+    if (d->kind == MRIRT_INR_FOURIER_RELU && d->inDim != 3 + 6 * d->fourierFreqs + d->numMods) return MRIRT_ERR_ARG;
+    if (d->kind == MRIRT_INR_SIREN && d->inDim != 3 + d->numMods) return MRIRT_ERR_ARG;
+    L.numLayers = d->numLayers; L.hidden = d->hidden; L.inDim = d->inDim; L.outDim = d->outDim;
+    L.kt0 = d->inDim <= 32 ? 1 : 4;                      // 33..128 inputs: zero-padded to 128 (layer 0 only)
+    uint32_t frag = 0, bias = 0, w = 0;
+    for (uint32_t l = 0; l < d->numLayers; ++l) {
+        L.in[l] = l == 0 ? d->inDim : d->hidden;
+        L.out[l] = l + 1 == d->numLayers ? d->outDim : d->hidden;
+        const uint32_t kt = l == 0 ? L.kt0 : d->hidden / 32, ot = (L.out[l] + 31) / 32;
+        L.fragOff[l] = frag; L.biasOff[l] = bias; L.wOff[l] = w;
+        frag += ot * kt * 2 * (l == 0 ? 2 : 1);          // layer 0 stores a hi and a lo image
+        bias += ot * 32;
+        w += L.in[l] * L.out[l];
+    }
+    L.totalFrags = frag;
+    return MRIRT_OK;
+}
+
+__device__ __forceinline__ uint16_t bf16_bits(float x) {     // round-to-nearest-even, NaN preserved by the cast
+    return __builtin_bit_cast(uint16_t, (__bf16)x);
+}
+
+// fp32 [in][out] row-major -> permuted bf16 fragments (see file header).  One thread per (fragment, lane).
+__global__ __launch_bounds__(256) void inr_pack_kernel(const float* __restrict__ w, uint4* __restrict__ packed, InrLayout L) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t frag = gid >> 6, lane = gid & 63u;
+    if (frag >= L.totalFrags) return;
+    uint32_t l = 0;
+    while (l + 1 < L.numLayers && frag >= L.fragOff[l + 1]) ++l;
+    const uint32_t kt = l == 0 ? L.kt0 : L.hidden / 32, ot = (L.out[l] + 31) / 32;
+    uint32_t f = frag - L.fragOff[l];
+    const bool lo = l == 0 && f >= ot * kt * 2;
+    if (lo) f -= ot * kt * 2;
+    const uint32_t s = f & 1u, t = (f >> 1) % kt, o = (f >> 1) / kt;
+    const uint32_t r = lane & 31u, h = lane >> 5;
+    uint16_t e[8];
+#pragma unroll
+    for (uint32_t j = 0; j < 8; ++j) {
+        const uint32_t k = 32 * t + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3u), oc = 32 * o + r;
+        const float v = (k < L.in[l] && oc < L.out[l]) ? w[L.wOff[l] + k * L.out[l] + oc] : 0.0f;
+        const uint16_t hi = bf16_bits(v);
+        const float hif = __builtin_bit_cast(float, (uint32_t)hi << 16);
+        e[j] = lo ? bf16_bits(v - hif) : hi;
+    }
+    uint4 q;
+    q.x = e[0] | ((uint32_t)e[1] << 16); q.y = e[2] | ((uint32_t)e[3] << 16);
+    q.z = e[4] | ((uint32_t)e[5] << 16); q.w = e[6] | ((uint32_t)e[7] << 16);
+    packed[(size_t)frag * 64 + lane] = q;
+}
+
+struct InrArgs {
+    InrLayout L;
+    uint32_t kind, K, M;
+    float w0;
+    const uint4* wpack;
+    const float* bias;
+    const float* coords;       // [n][3] or nullptr (volume mode / raw-x kinds)
+    const float* feats;        // [n][M]  (points mode)  or mods[M][H*W*D] (volume mode)
+    int64_t n;
+    uint32_t volume;           // 1: points are the voxels of an H x W x D grid in ij order
+    uint32_t H, W, D;
+    float* logits;
+    int16_t* argmax;
+};
+
+// value of input feature f for point p (inr/inr/model.py:11-23 feature order)
+__device__ __forceinline__ float input_feature(const InrArgs& a, uint32_t f, int64_t p, const float c[3]) {
+    if (f >= a.L.inDim) return 0.0f;
+    const bool raw = a.kind >= 2;
+    const uint32_t nc = raw ? 0u : 3u;
+    if (f < nc) return c[f];
+    uint32_t g = f - nc;
+    if (a.kind == MRIRT_INR_FOURIER_RELU) {
+        if (g < 6 * a.K) {
+            const uint32_t axis = g / (2 * a.K), rem = g % (2 * a.K);
+            const bool isSin = rem < a.K;
+            const float ang = (c[axis] * (float)((isSin ? rem : rem - a.K) + 1)) * 3.14159274101257324f;
+            return isSin ? sinf(ang) : cosf(ang);
+        }
+        g -= 6 * a.K;
+    }
+    return a.volume ? a.feats[(size_t)g * ((size_t)a.H * a.W * a.D) + p] : a.feats[p * (int64_t)a.M + g];
+}
+
+template <int HID, int KT0>
+__global__ __launch_bounds__(256) void inr_forward_kernel(const InrArgs a) {
+    constexpr int KT = HID / 32;
+    const uint32_t lane = threadIdx.x & 63u, r = lane & 31u, h = lane >> 5;
+    const int64_t waveId = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t base = waveId * (kPT * 32);
+    if (base >= a.n) return;
+    const uint4* __restrict__ wp = a.wpack;
+    const bool siren = a.kind == MRIRT_INR_SIREN || a.kind == 3u;
+
+    // ---- layer-0 B operands: this lane's point, features 16s + 8(j>>2) + 4h + (j&3) of k tile t --------
+    bf16x8 xin_hi[kPT][KT0][2], xin_lo[kPT][KT0][2];
+    int64_t pidx[kPT];
+#pragma unroll
+    for (int pt = 0; pt < kPT; ++pt) {
+        int64_t p = base + pt * 32 + r;
+        pidx[pt] = p;
+        const bool valid = p < a.n;
+        if (!valid) p = a.n - 1;                         // clamp: compute something, store nothing
+        float c[3] = { 0.0f, 0.0f, 0.0f };
+        if (a.volume) {                                  // model.py:124-128, fp64 then one rounding to fp32
+            const uint32_t k = (uint32_t)(p % a.D), j = (uint32_t)((p / a.D) % a.W), i = (uint32_t)(p / ((int64_t)a.D * a.W));
+            c[0] = (float)(((double)i / (double)(a.H - 1)) * 2.0 - 1.0);
+            c[1] = (float)(((double)j / (double)(a.W - 1)) * 2.0 - 1.0);
+            c[2] = (float)(((double)k / (double)(a.D - 1)) * 2.0 - 1.0);
+        } else if (a.coords) {
+            c[0] = a.coords[p * 3 + 0]; c[1] = a.coords[p * 3 + 1]; c[2] = a.coords[p * 3 + 2];
+        }
+#pragma unroll
+        for (int t = 0; t < KT0; ++t)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const uint32_t f = 32 * t + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3);
+                    const float v = input_feature(a, f, p, c);
+                    const __bf16 hi = (__bf16)v;
+                    xin_hi[pt][t][s][j] = hi;
+                    xin_lo[pt][t][s][j] = (__bf16)(v - (float)hi);
+                }
+    }
+
+    bf16x8 Hc[kPT][KT][2];       // current layer's input, as B operands
+    bf16x8 Hn[kPT][KT][2];       // next layer's input, built out-tile by out-tile
+
+    auto activate = [&](const f32x16& acc, const float* __restrict__ bias, uint32_t o, bool first, int pt) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = 8 * s + j;
+                const uint32_t row = 32 * o + (i & 3) + 8 * (i >> 2) + 4 * h;
+                float x = acc[i];
+                if (siren) x = __builtin_sinf((first ? a.w0 * x : x) + bias[row]);     // neumors_inr.ipynb:1165-1178
+                else x = fmaxf(x + bias[row], 0.0f);                                    // model.py:46-48
+                Hn[pt][o][s][j] = (__bf16)x;
+            }
+    };
+
+    // ---- layer 0: hi/lo split, three products ---------------------------------------------------------
+    {
+        const uint32_t imgLo = (HID / 32) * KT0 * 2;     // fragments in the hi image (out tiles x k tiles x 2)
+        const float* __restrict__ b0 = a.bias + a.L.biasOff[0];
+#pragma unroll
+        for (int o = 0; o < KT; ++o) {                   // out tiles of a hidden-wide layer == KT
+            f32x16 acc[kPT];
+#pragma unroll
+            for (int pt = 0; pt < kPT; ++pt) acc[pt] = (f32x16)(0.0f);
+#pragma unroll
+            for (int t = 0; t < KT0; ++t)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const uint32_t fr = a.L.fragOff[0] + ((o * KT0 + t) * 2 + s);
+                    const bf16x8 whi = __builtin_bit_cast(bf16x8, wp[(size_t)fr * 64 + lane]);
+                    const bf16x8 wlo = __builtin_bit_cast(bf16x8, wp[(size_t)(fr + imgLo) * 64 + lane]);
+#pragma unroll
+                    for (int pt = 0; pt < kPT; ++pt) {
+                        acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo, xin_hi[pt][t][s], acc[pt], 0, 0, 0);
+                        acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi, xin_lo[pt][t][s], acc[pt], 0, 0, 0);
+                        acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi, xin_hi[pt][t][s], acc[pt], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+            for (int pt = 0; pt < kPT; ++pt) activate(acc[pt], b0, o, true, pt);
+        }
+    }
+
+    // ---- hidden layers 1 .. L-2 ----------------------------------------------------------------------------
+    for (uint32_t l = 1; l + 1 < a.L.numLayers; ++l) {
+#pragma unroll
+        for (int pt = 0; pt < kPT; ++pt)
+#pragma unroll
+            for (int t = 0; t < KT; ++t) { Hc[pt][t][0] = Hn[pt][t][0]; Hc[pt][t][1] = Hn[pt][t][1]; }
+        const uint32_t f0 = a.L.fragOff[l];
+        const float* __restrict__ bl = a.bias + a.L.biasOff[l];
+#pragma unroll
+        for (int o = 0; o < KT; ++o) {
+            f32x16 acc[kPT];
+#pragma unroll
+            for (int pt = 0; pt < kPT; ++pt) acc[pt] = (f32x16)(0.0f);
+#pragma unroll
+            for (int t = 0; t < KT; ++t)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const bf16x8 wf = __builtin_bit_cast(bf16x8, wp[(size_t)(f0 + (o * KT + t) * 2 + s) * 64 + lane]);
+#pragma unroll
+                    for (int pt = 0; pt < kPT; ++pt)
+                        acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, Hc[pt][t][s], acc[pt], 0, 0, 0);
+                }
+#pragma unroll
+            for (int pt = 0; pt < kPT; ++pt) activate(acc[pt], bl, o, false, pt);
+        }
+    }
+
+    // ---- head: one out tile (outDim <= 16 rows used), linear ---------------------------------------------------
+    {
+        const uint32_t l = a.L.numLayers - 1, f0 = a.L.fragOff[l];
+        const float* __restrict__ bl = a.bias + a.L.biasOff[l];
+        f32x16 acc[kPT];
+#pragma unroll
+        for (int pt = 0; pt < kPT; ++pt) acc[pt] = (f32x16)(0.0f);
+#pragma unroll
+        for (int t = 0; t < KT; ++t)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8 wf = __builtin_bit_cast(bf16x8, wp[(size_t)(f0 + t * 2 + s) * 64 + lane]);
+#pragma unroll
+                for (int pt = 0; pt < kPT; ++pt)
+                    acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, Hn[pt][t][s], acc[pt], 0, 0, 0);
+            }
+#pragma unroll
+        for (int pt = 0; pt < kPT; ++pt) {
+            const int64_t p = pidx[pt];
+            float best = -INFINITY;
+            uint32_t bestc = 0xffffu;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const uint32_t cls = (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (cls < a.L.outDim) {
+                    const float v = acc[pt][i] + bl[cls];
+                    if (a.logits && p < a.n) a.logits[p * a.L.outDim + cls] = v;
+                    if (v > best || (v == best && cls < bestc)) { best = v; bestc = cls; }    // np.argmax: first maximum
+                }
+            }
+            const float ob = __shfl_xor(best, 32);
+            const uint32_t oc = __shfl_xor(bestc, 32);
+            if (ob > best || (ob == best && oc < bestc)) { best = ob; bestc = oc; }
+            if (a.argmax && h == 0 && p < a.n) a.argmax[p] = (int16_t)bestc;
+        }
+    }
+}
+
+template <int HID>
+static int launch_inr_kt0(const InrArgs& a, hipStream_t s) {
+    const int64_t waves = (a.n + kPT * 32 - 1) / (kPT * 32);
+    const dim3 grid((uint32_t)((waves + 3) / 4)), block(256);
+    if (a.L.kt0 == 1) hipLaunchKernelGGL((inr_forward_kernel<HID, 1>), grid, block, 0, s, a);
+    else              hipLaunchKernelGGL((inr_forward_kernel<HID, 4>), grid, block, 0, s, a);
+    MRIRT_HIP(hipGetLastError());
+    return MRIRT_OK;
+}
+
+static int launch_inr(const InrArgs& a, hipStream_t s) {
+    if (a.n <= 0) return MRIRT_OK;
+    switch (a.L.hidden) {
+        case 32: return launch_inr_kt0<32>(a, s);
+        case 64: return launch_inr_kt0<64>(a, s);
+        case 128: return launch_inr_kt0<128>(a, s);
+        default: return launch_inr_kt0<256>(a, s);
+    }
+}
+
+static int fill_args(const MrirtInrDesc* d, InrArgs& a) {
+    int rc = make_layout(d, a.L);
+    if (rc != MRIRT_OK) return rc;
+    if (!d->weights || !d->biases) return MRIRT_ERR_NULL;
+    a.kind = d->kind; a.K = d->fourierFreqs; a.M = d->numMods; a.w0 = d->w0;
+    a.wpack = static_cast<const uint4*>(d->weights);
+    a.bias = d->biases;
+    a.coords = nullptr; a.feats = nullptr; a.n = 0; a.volume = 0; a.H = a.W = a.D = 1;
+    a.logits = nullptr; a.argmax = nullptr;
+    return MRIRT_OK;
+}
+
+}  // namespace mrirt
+
+using namespace mrirt;
+
+extern "C" int64_t mrirt_inr_pack_bytes(const MrirtInrDesc* desc) {
+    InrLayout L;
+    if (make_layout(desc, L) != MRIRT_OK) return 0;
+    return (int64_t)L.totalFrags * 1024;
+}
+
+extern "C" int mrirt_inr_pack_weights(const MrirtInrDesc* desc, const float* w_f32, void* packed, void* stream) {
+    InrLayout L;
+    int rc = make_layout(desc, L);
+    if (rc != MRIRT_OK) return rc;
+    if (!w_f32 || !packed) return MRIRT_ERR_NULL;
+    const uint32_t threads = L.totalFrags * 64;
+    hipLaunchKernelGGL(inr_pack_kernel, dim3((threads + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       w_f32, static_cast<uint4*>(packed), L);
+    MRIRT_HIP(hipGetLastError());
+    return MRIRT_OK;
+}
+
+extern "C" int mrirt_inr_forward(const MrirtInrDesc* desc, const float* coords, const float* feats, int64_t n,
+                                 float* logits, int16_t* argmax, void* stream) {
+    InrArgs a;
+    int rc = fill_args(desc, a);
+    if (rc != MRIRT_OK) return rc;
+    if (n < 0) return MRIRT_ERR_ARG;
+    const bool needCoords = desc->kind < 2, needFeats = desc->kind >= 2 || desc->numMods > 0;
+    if ((needCoords && !coords) || (needFeats && !feats)) return MRIRT_ERR_NULL;
+    if (!logits && !argmax) return MRIRT_ERR_NULL;
+    if (desc->kind >= 2) a.M = desc->inDim;              // raw-x kinds: feats IS the input matrix [n][inDim]
+    a.coords = desc->kind < 2 ? coords : nullptr;
+    a.feats = feats; a.n = n; a.logits = logits; a.argmax = argmax;
+    return launch_inr(a, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int mrirt_inr_predict_volume(const MrirtInrDesc* desc, const float* mods, const uint32_t hwd[3],
+                                        int16_t* pred, void* stream) {
+    InrArgs a;
+    int rc = fill_args(desc, a);
+    if (rc != MRIRT_OK) return rc;
+    if (!mods || !hwd || !pred) return MRIRT_ERR_NULL;
+    if (desc->kind != MRIRT_INR_FOURIER_RELU && desc->kind != MRIRT_INR_SIREN) return MRIRT_ERR_ARG;
+    for (int k = 0; k < 3; ++k) if (hwd[k] < 2) return MRIRT_ERR_DIMS;
+    a.feats = mods; a.volume = 1; a.H = hwd[0]; a.W = hwd[1]; a.D = hwd[2];
+    a.n = (int64_t)hwd[0] * hwd[1] * hwd[2];
+    a.argmax = pred;
+    return launch_inr(a, static_cast<hipStream_t>(stream));
+}

@@ -1,0 +1,194 @@
+"""INR forward on the GPU, with the reference's names and argument meaning.
+
+Mirrors ``inr/inr/model.py`` as the viewer and notebooks use it (``from inr.model import
+model_load, predict_volume``: inr/interactive.ipynb cell 5, inr/viewer/brats_viewer.py:261,293):
+
+  model_load(npz_path, config_override=None) -> (params, config)        model.py:217-301
+  build_input(coords, intensities, fourier_freqs) -> (B, 3+6K+M)        model.py:21-23
+  apply_mlp(params, x) -> logits                                        model.py:43-50
+  predict_volume(params, case_data, fourier_freqs, chunk) -> (pred,seg) model.py:119-141
+  siren_apply(params, x, w0=30)                                         neumors_inr.ipynb:1165-1178
+
+``params`` is the reference's list of ``{"W": [in,out], "b": [out]}`` (SIREN: dict ``l{i}`` ->
+``{"w","b"}``).  All arithmetic runs in csrc/inr_mlp.hip (bf16 MFMA, fp32 accumulate, split-bf16
+first layer); ``model_load`` is host-side file parsing.  No CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import pathlib
+from dataclasses import dataclass
+from typing import Any, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from .render import _ptr, _require_gpu, _stream_ptr
+
+KIND_FOURIER_RELU, KIND_SIREN, KIND_RAW_RELU, KIND_RAW_SIREN = 0, 1, 2, 3
+
+
+def model_load(npz_path, config_override: Optional[Dict[str, Any]] = None) -> Tuple[List[Dict[str, np.ndarray]], Dict[str, Any]]:
+    """Checkpoint reader: ``{name}.npz`` + sidecar ``{name}_info.json`` (model.py:248-301).
+
+    Accepts the final-checkpoint layout (key ``params`` holding a pickled list of W/b dicts,
+    train.py:386-389 — needs ``allow_pickle`` and is therefore only honoured for files the caller
+    trusts: pass ``config_override={"ALLOW_PICKLE": True}``) and the periodic-checkpoint layout
+    (flat ``W_i`` / ``b_i`` arrays, train.py:216-223), which needs no pickle.
+    """
+    path = pathlib.Path(npz_path).expanduser().resolve()
+    if not path.is_file():
+        raise FileNotFoundError(f"NPZ file not found: {path}")
+    cfg_path = path.with_name(f"{path.stem}_info.json")
+    if not cfg_path.is_file():
+        raise FileNotFoundError(f"Config JSON not found next to NPZ: {cfg_path}")
+    allow_pickle = bool((config_override or {}).get("ALLOW_PICKLE", False))
+    with np.load(str(path), allow_pickle=allow_pickle) as z:
+        names = list(z.files)
+        if names and all(n.startswith(("W_", "b_")) for n in names):
+            count = sum(n.startswith("W_") for n in names)
+            params = [{"W": np.asarray(z[f"W_{i}"]), "b": np.asarray(z[f"b_{i}"])} for i in range(count)]
+        elif "params" in names or len(names) == 1:
+            key = "params" if "params" in names else names[0]
+            try:
+                arr = z[key]
+            except ValueError as exc:
+                raise ValueError(f"{path} stores pickled params; pass config_override={{'ALLOW_PICKLE': True}} "
+                                 "only for checkpoints you trust") from exc
+            if arr.dtype == object:
+                if arr.ndim != 0 and arr.size != 1:
+                    raise ValueError(f"'{key}' in {path} is an object array with shape {arr.shape}; "
+                                     "expected a single serialized object.")
+                params = arr.item()
+            else:
+                params = arr
+        else:
+            raise KeyError(f"Could not find 'params' key in {path}; available keys: {names}")
+    config = json.loads(cfg_path.read_text())
+    if config_override is not None:
+        config = {**config, **{k: v for k, v in config_override.items() if k != "ALLOW_PICKLE"}}
+    return params, config
+
+
+def fourier_features(coords, k: int) -> torch.Tensor:
+    """model.py:11-18: per axis [sin(pi 1 c) .. sin(pi k c), cos(pi 1 c) .. cos(pi k c)] -> (B, 6k)."""
+    dev = _require_gpu()
+    c = _dev_f32(coords, dev)
+    freqs = torch.arange(1, k + 1, device=dev, dtype=torch.float32)
+    ang = c[..., None] * freqs[None, None, :] * np.float32(np.pi)
+    return torch.cat([torch.sin(ang), torch.cos(ang)], dim=-1).reshape(c.shape[0], -1)
+
+
+@dataclass
+class PackedMLP:
+    """Device-resident network: permuted bf16 weight fragments + padded fp32 biases."""
+    desc: _lib.InrDesc
+    weights: torch.Tensor
+    biases: torch.Tensor
+    in_dim: int
+    out_dim: int
+
+
+def _layers(params) -> List[Tuple[np.ndarray, np.ndarray]]:
+    if isinstance(params, dict):                         # SIREN notebook layout: l0, l1, ...
+        return [(np.asarray(params[f"l{i}"]["w"], np.float32), np.asarray(params[f"l{i}"]["b"], np.float32))
+                for i in range(len(params))]
+    return [(np.asarray(p["W"], np.float32), np.asarray(p["b"], np.float32)) for p in params]
+
+
+def pack_mlp(params, kind: int, fourier_freqs: int = 0, num_mods: int = 0, w0: float = 30.0) -> PackedMLP:
+    dev = _require_gpu()
+    layers = _layers(params)
+    if len(layers) < 2:
+        raise ValueError("the MLP kernel needs at least one hidden layer")
+    hidden = layers[0][0].shape[1]
+    for i, (W, b) in enumerate(layers):
+        want_in = layers[0][0].shape[0] if i == 0 else hidden
+        want_out = hidden if i + 1 < len(layers) else W.shape[1]
+        if W.shape != (want_in, want_out) or b.shape != (want_out,):
+            raise ValueError(f"layer {i}: W {W.shape} / b {b.shape}; the kernel needs equal hidden widths ({hidden})")
+    d = _lib.InrDesc()
+    d.kind, d.numLayers, d.inDim, d.outDim, d.hidden = kind, len(layers), layers[0][0].shape[0], layers[-1][0].shape[1], hidden
+    d.fourierFreqs, d.numMods, d.w0 = int(fourier_freqs), int(num_mods), float(w0)
+    nbytes = int(_lib.lib().mrirt_inr_pack_bytes(C.byref(d)))
+    if nbytes <= 0:
+        raise ValueError(f"unsupported network shape: in {d.inDim}, hidden {hidden} x {len(layers) - 1}, out {d.outDim} "
+                         "(hidden in {32,64,128,256}, in <= 128, out <= 16, <= 8 layers)")
+    w_flat = torch.from_numpy(np.concatenate([W.reshape(-1) for W, _ in layers])).to(dev)
+    bias = np.concatenate([np.pad(b, (0, (-b.size) % 32)) for _, b in layers]).astype(np.float32)
+    packed = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    biases = torch.from_numpy(bias).to(dev)
+    d.weights, d.biases = packed.data_ptr(), biases.data_ptr()
+    _lib.check(_lib.lib().mrirt_inr_pack_weights(C.byref(d), _ptr(w_flat), _ptr(packed), _stream_ptr(None)),
+               "mrirt_inr_pack_weights")
+    torch.cuda.current_stream().synchronize()           # w_flat may be freed after this returns
+    return PackedMLP(d, packed, biases, int(d.inDim), int(d.outDim))
+
+
+def _forward(net: PackedMLP, coords, feats, n: int, want_logits: bool, want_argmax: bool):
+    dev = net.weights.device
+    logits = torch.empty((n, net.out_dim), dtype=torch.float32, device=dev) if want_logits else None
+    arg = torch.empty(n, dtype=torch.int16, device=dev) if want_argmax else None
+    rc = _lib.lib().mrirt_inr_forward(C.byref(net.desc), _ptr(coords), _ptr(feats), n, _ptr(logits), _ptr(arg),
+                                      _stream_ptr(None))
+    _lib.check(rc, "mrirt_inr_forward")
+    return logits, arg
+
+
+def _dev_f32(x, dev):
+    return torch.as_tensor(np.asarray(x, dtype=np.float32) if not isinstance(x, torch.Tensor) else x,
+                           dtype=torch.float32).to(dev).contiguous()
+
+
+def build_input(coords, intensities, fourier_freqs: int) -> torch.Tensor:
+    """(B,3) coords in [-1,1], (B,M) intensities -> (B, 3+6K+M) input matrix in the reference's
+    feature order.  Provided for API parity; ``inr_forward`` builds the same features in-kernel."""
+    dev = _require_gpu()
+    c, f = _dev_f32(coords, dev), _dev_f32(intensities, dev)
+    return torch.cat([c, fourier_features(c, fourier_freqs), f], dim=-1)
+
+
+def inr_forward(params, coords, feats, fourier_freqs: int, net: Optional[PackedMLP] = None):
+    """logits (B, classes) fp32 for points: Fourier features + ReLU MLP, fused."""
+    dev = _require_gpu()
+    f = _dev_f32(feats, dev)
+    net = net or pack_mlp(params, KIND_FOURIER_RELU, fourier_freqs, f.shape[1])
+    c = _dev_f32(coords, dev)
+    return _forward(net, c, f, c.shape[0], True, False)[0]
+
+
+def apply_mlp(params, x, net: Optional[PackedMLP] = None) -> torch.Tensor:
+    """model.py:43-50 on an already-built input matrix x (B, in_dim)."""
+    dev = _require_gpu()
+    xx = _dev_f32(x, dev)
+    net = net or pack_mlp(params, KIND_RAW_RELU)
+    return _forward(net, None, xx, xx.shape[0], True, False)[0]
+
+
+def siren_apply(params, x, w0: float = 30.0, net: Optional[PackedMLP] = None) -> torch.Tensor:
+    dev = _require_gpu()
+    xx = _dev_f32(x, dev)
+    net = net or pack_mlp(params, KIND_RAW_SIREN, w0=w0)
+    return _forward(net, None, xx, xx.shape[0], True, False)[0]
+
+
+def predict_volume(params, case_data: Dict[str, Any], fourier_freqs: int, chunk: int = 200000,
+                   net: Optional[PackedMLP] = None):
+    """model.py:119-141: argmax class per voxel of ``case_data["mods"]`` (M,H,W,D) -> int16 (H,W,D).
+    ``chunk`` is accepted for signature parity; the kernel streams the whole volume in one launch."""
+    dev = _require_gpu()
+    mods = _dev_f32(case_data["mods"], dev)
+    M, H, W, D = mods.shape
+    net = net or pack_mlp(params, KIND_FOURIER_RELU, fourier_freqs, M)
+    pred = torch.empty((H, W, D), dtype=torch.int16, device=dev)
+    hwd = (C.c_uint32 * 3)(H, W, D)
+    rc = _lib.lib().mrirt_inr_predict_volume(C.byref(net.desc), _ptr(mods), hwd, _ptr(pred), _stream_ptr(None))
+    _lib.check(rc, "mrirt_inr_predict_volume")
+    return pred, case_data.get("seg")
+
+
+def labels_for_viewer(pred_hwd: torch.Tensor) -> torch.Tensor:
+    """pred (H,W,D) -> the viewer's x-fastest uint32 label buffer (brats_viewer.py:297-299)."""
+    return pred_hwd.permute(2, 1, 0).reshape(-1).to(torch.int32).contiguous()

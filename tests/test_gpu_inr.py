@@ -1,0 +1,105 @@
+"""INR forward (bf16 MFMA) against the goldens captured from the reference's inr/inr/model.py and
+against the fp32 oracle.  Tolerances: the kernel multiplies in bf16 (split-bf16
+first layer, fp32 accumulate), so logits are held to a relative bound scaled by the logit range
+and the classifier to argmax agreement; every disagreement must be a near-tie in the fp32 logits."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_REL_TOL = 2e-2        # of max|logit|: bf16 hidden layers (8-bit mantissa), 4 layers deep
+ARGMAX_AGREE = 0.995
+
+
+@pytest.fixture(scope="module")
+def env(golden_dir):
+    import torch
+    import mrirt
+    from oracle import oracle_np
+    assert torch.cuda.is_available()
+    return dict(torch=torch, mrirt=mrirt, onp=oracle_np, g=np.load(golden_dir / "inr_fourier.npz"),
+                s=np.load(golden_dir / "siren.npz"))
+
+
+def _params(g, tag, n):
+    return [{"W": g[f"{tag}_W{i}"], "b": g[f"{tag}_b{i}"]} for i in range(n)]
+
+
+@pytest.mark.parametrize("tag,nl", [("k4h64", 5), ("k16h256", 5), ("k2h32x2", 3)])
+def test_fourier_mlp_matches_reference_goldens(env, tag, nl):
+    mrirt, g = env["mrirt"], env["g"]
+    K = int(g[f"{tag}_K"])
+    params = _params(g, tag, nl)
+    want = g[f"{tag}_logits"]
+    scale = np.abs(want).max()
+    # fused: coords + intensities in, features built in-kernel
+    got = mrirt.inr.inr_forward(params, g[f"{tag}_coords"], g[f"{tag}_feats"], K).cpu().numpy()
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() <= LOGIT_REL_TOL * scale, np.abs(got - want).max() / scale
+    # apply_mlp on the reference's own input matrix
+    got2 = mrirt.inr.apply_mlp(params, g[f"{tag}_x"].astype(np.float32)).cpu().numpy()
+    assert np.abs(got2 - want).max() <= LOGIT_REL_TOL * scale
+    # build_input reproduces the reference's feature matrix (order and values)
+    x = mrirt.inr.build_input(g[f"{tag}_coords"], g[f"{tag}_feats"], K).cpu().numpy()
+    assert x.shape == g[f"{tag}_x"].shape and np.abs(x - g[f"{tag}_x"]).max() < 2e-6 * max(4, K)
+
+
+@pytest.mark.parametrize("tag,nl", [("k4h64", 5), ("k16h256", 5), ("k2h32x2", 3)])
+def test_predict_volume_matches_reference_goldens(env, tag, nl):
+    mrirt, g, onp = env["mrirt"], env["g"], env["onp"]
+    K = int(g[f"{tag}_K"])
+    params = _params(g, tag, nl)
+    pred, seg = mrirt.inr.predict_volume(params, {"mods": g["mods"], "seg": None}, K)
+    pred = pred.cpu().numpy()
+    want = g[f"{tag}_pred"]
+    assert pred.dtype == np.int16 and pred.shape == want.shape and seg is None
+    # 120 voxels: every disagreement must be a near-tie of the top two fp32 logits
+    bad = np.argwhere(pred != want)
+    if len(bad):
+        H, W, D = want.shape
+        grid = np.stack(np.meshgrid(np.arange(H), np.arange(W), np.arange(D), indexing="ij"), -1).reshape(-1, 3)
+        norm = ((grid / np.array([H - 1, W - 1, D - 1])) * 2.0 - 1.0).astype(np.float32)
+        x = onp.build_input(norm, g["mods"].transpose(1, 2, 3, 0).reshape(-1, 4), K)
+        logits = onp.apply_mlp(params, x).reshape(H, W, D, -1)
+        for i, j, k in bad:
+            top = np.sort(logits[i, j, k])[-2:]
+            assert top[1] - top[0] <= LOGIT_REL_TOL * np.abs(logits).max()
+    assert (pred == want).mean() >= 0.97
+
+
+def test_predict_volume_large_agreement(env):
+    """A 48x40x36 volume (69k voxels, ragged vs the 64-point wave tile) against the fp32 oracle."""
+    mrirt, onp = env["mrirt"], env["onp"]
+    rng = np.random.default_rng(11)
+    K, M, hidden = 4, 4, 64
+    dims = [3 + 6 * K + M] + [hidden] * 4 + [4]
+    params = [{"W": rng.uniform(-1, 1, (dims[i], dims[i + 1])).astype(np.float32) * np.float32(np.sqrt(6 / (dims[i] + dims[i + 1]))),
+               "b": rng.uniform(-0.1, 0.1, dims[i + 1]).astype(np.float32)} for i in range(5)]
+    mods = rng.standard_normal((M, 48, 40, 36)).astype(np.float32)
+    want, _ = onp.predict_volume(params, {"mods": mods, "seg": None}, K)
+    got, _ = mrirt.inr.predict_volume(params, {"mods": mods, "seg": None}, K)
+    agree = (got.cpu().numpy() == want).mean()
+    assert agree >= ARGMAX_AGREE, agree
+    lab = mrirt.inr.labels_for_viewer(got).cpu().numpy()
+    assert np.array_equal(lab, got.cpu().numpy().transpose(2, 1, 0).reshape(-1))
+
+
+@pytest.mark.parametrize("tag,depth", [("s3x256", 3), ("s4x256", 4)])
+def test_siren_matches_fp64_fixture(env, tag, depth):
+    mrirt, s = env["mrirt"], env["s"]
+    params = {f"l{i}": {"w": s[f"{tag}_l{i}_w"], "b": s[f"{tag}_l{i}_b"]} for i in range(depth + 1)}
+    want = s[f"{tag}_logits"]
+    got = mrirt.inr.siren_apply(params, s[f"{tag}_x"]).cpu().numpy()
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() <= 3e-2 * max(1.0, np.abs(want).max())
+
+
+def test_inr_argument_errors(env):
+    mrirt = env["mrirt"]
+    rng = np.random.default_rng(0)
+    bad = [{"W": rng.random((7, 48)).astype(np.float32), "b": np.zeros(48, np.float32)},
+           {"W": rng.random((48, 4)).astype(np.float32), "b": np.zeros(4, np.float32)}]
+    with pytest.raises(ValueError):
+        mrirt.inr.pack_mlp(bad, mrirt.inr.KIND_RAW_RELU)          # hidden 48 unsupported
+    with pytest.raises(ValueError):
+        mrirt.inr.pack_mlp(bad[:1], mrirt.inr.KIND_RAW_RELU)      # no hidden layer

@@ -156,3 +156,27 @@ def test_synth_is_deterministic_and_in_range():
     lab = synth.synth_labels(16)
     assert set(np.unique(lab)) <= {0, 1, 2, 3} and lab.dtype == np.uint32
     assert not np.array_equal(a, synth.synth_volume(16, seed=1235))
+
+
+def test_model_load_both_layouts(golden_dir, tmp_path):
+    import json
+    g = np.load(golden_dir / "inr_fourier.npz")
+    params = [{"W": g[f"k2h32x2_W{i}"], "b": g[f"k2h32x2_b{i}"]} for i in range(3)]
+    flat = {}
+    for i, p in enumerate(params):
+        flat[f"W_{i}"], flat[f"b_{i}"] = p["W"], p["b"]
+    np.savez(tmp_path / "ckpt.npz", **flat)
+    (tmp_path / "ckpt_info.json").write_text(json.dumps({"config": {"FOURIER_FREQS": 2}, "NUM_CLASSES": 4}))
+    got, cfg = mrirt.inr.model_load(tmp_path / "ckpt.npz", config_override={"DATA_ROOT": "/x"})
+    assert cfg["config"]["FOURIER_FREQS"] == 2 and cfg["DATA_ROOT"] == "/x"
+    assert all(np.array_equal(a["W"], b["W"]) and np.array_equal(a["b"], b["b"]) for a, b in zip(got, params))
+    arr = np.empty((), dtype=object)
+    arr[()] = params
+    np.savez(tmp_path / "final.npz", params=arr)
+    (tmp_path / "final_info.json").write_text("{}")
+    with pytest.raises(ValueError):
+        mrirt.inr.model_load(tmp_path / "final.npz")                               # pickle refused by default
+    got2, _ = mrirt.inr.model_load(tmp_path / "final.npz", config_override={"ALLOW_PICKLE": True})
+    assert np.array_equal(got2[0]["W"], params[0]["W"])
+    with pytest.raises(FileNotFoundError):
+        mrirt.inr.model_load(tmp_path / "missing.npz")
