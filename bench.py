@@ -58,6 +58,17 @@ def parse():
     return ap.parse_args()
 
 
+def measured_traffic(key):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json), or
+    None when this configuration has not been profiled."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
+            entry = json.load(fh).get(key)
+        return int(entry["hbm_bytes_per_launch"]) if entry else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def cpu_baseline(params, vol, ext, rows, n_image):
     """The C/OpenMP oracle (oracle/oracle_c.c) timed on the host cores, on a band of rows of the
     same frame.  A reported baseline, not the target."""
@@ -192,7 +203,10 @@ def main():
                        "nominal_samples_per_frame": image * image * a.march_steps,
                        "kernel_variant": a.variant},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": measured_traffic(
+                             f"{'C3' if not a.no_shade else 'K1'}:{n}:{image}:{a.march_steps}:{a.layout}:{a.math}:"
+                             f"{'shade' if not a.no_shade else 'plain'}") if world == 1 and a.variant == 0 and a.alpha == 16.0 else None,
                          "kernel": "brats_march_kernel", "kernel_ms": round(kernel_ms, 4),
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "bytes_per_sample": BYTES_PER_SAMPLE + (0 if a.no_shade else BYTES_PER_SHADED)},
