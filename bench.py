@@ -207,7 +207,7 @@ def main():
                          "traffic": measured_traffic(
                              f"{'C3' if not a.no_shade else 'K1'}:{n}:{image}:{a.march_steps}:{a.layout}:{a.math}:"
                              f"{'shade' if not a.no_shade else 'plain'}") if world == 1 and a.variant == 0 and a.alpha == 16.0 else None,
-                         "kernel": "brats_march_kernel", "kernel_ms": round(kernel_ms, 4),
+                         "kernel": "brats_march_pipe_kernel" if not a.variant & 4 else "brats_march_kernel", "kernel_ms": round(kernel_ms, 4),
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "bytes_per_sample": BYTES_PER_SAMPLE + (0 if a.no_shade else BYTES_PER_SHADED)},
         }

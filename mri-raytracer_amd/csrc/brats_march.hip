@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void brats_march_kernel(const K1Args a) {
 // then waits with vmcnt(#gathers of one stage) instead of vmcnt(0).
 // ---------------------------------------------------------------------------------------
 template <bool STRICT, int LAYOUT, bool SHADE>
-__global__ __launch_bounds__(256) void brats_march_pipe_kernel(const K1Args a) {
+__global__ __launch_bounds__(256, 3) void brats_march_pipe_kernel(const K1Args a) {
     using Mm = M<STRICT>;
     uint32_t px, py;
     int64_t oidx;

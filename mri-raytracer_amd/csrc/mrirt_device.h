@@ -78,8 +78,10 @@ template <> struct M<false> {
     static __device__ __forceinline__ float mad(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 };
 
-__device__ __forceinline__ float satf(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
-__device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+// v_med3_f32: one instruction; with a NaN input it returns min3 of the others, i.e. lo — the same
+// result as fminf(fmaxf(NaN, lo), hi) and as HLSL saturate(NaN) = 0 (requires lo <= hi).
+__device__ __forceinline__ float clampf(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
+__device__ __forceinline__ float satf(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 1.0f); }
 __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
     return (ax * bx + ay * by) + az * bz;
 }
