@@ -10,14 +10,18 @@
 // register file (guide: "an accumulator tile as the next MFMA's operand").  The k order inside a
 // 16-deep step is permuted by that reuse (element j of lane half h is feature 16s + 8(j>>2) + 4h + (j&3));
 // the weights are pre-packed in the same permuted order (mrirt_inr_pack_weights), one 1-KiB fragment
-// per (out tile, k step), so an A fragment is a single coalesced 16-byte load per lane.
+// per (out tile, k step): an A fragment is one 16-byte read per lane.
+//
+// Work split: a workgroup is 8 waves (2 per SIMD, so one wave's activations overlap the other's
+// MFMAs); each wave owns 32 points.  The weights of one out tile (<= 16 KiB) are a "chunk": chunks
+// are consecutive in the packed image, staged global -> registers -> LDS one chunk ahead (double
+// buffer, one barrier per chunk) and read by all 8 waves with conflict-free ds_read_b128.  Weight
+// traffic from L2 is thus 16 KiB per 256 points per chunk instead of per 64 points per wave.
 //
 // Precision: bf16 operands, fp32 accumulate.  The FIRST layer sees raw coordinates and Fourier
 // features (sin(pi k c), k <= 16) and, for the SIREN, a 30x frequency scale, so its inputs and weights
 // are split hi + lo in bf16 and three products are accumulated (hi*hi + hi*lo + lo*hi: ~16 mantissa
 // bits).  Hidden layers use plain bf16.
-//
-// One wave handles PT = 2 tiles of 32 points; a workgroup is 4 waves.
 #include "mrirt_host.h"
 
 namespace mrirt {
@@ -25,7 +29,7 @@ namespace mrirt {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kPT = 2;            // point tiles (of 32 points) per wave
+constexpr int kInrWaves = 8;      // waves per workgroup
 constexpr int kMaxLayers = 8;
 
 struct InrLayout {
@@ -37,6 +41,7 @@ struct InrLayout {
     uint32_t totalFrags;
 };
 
+// Packed image, in fragment units:  layer 0: [o][t][s][hi,lo]   other layers: [o][t][s]
 static int make_layout(const MrirtInrDesc* d, InrLayout& L) {
     if (!d) return MRIRT_ERR_NULL;
     if (d->numLayers < 2 || d->numLayers > kMaxLayers || d->outDim < 1 || d->outDim > 16) return MRIRT_ERR_ARG;
@@ -52,7 +57,7 @@ static int make_layout(const MrirtInrDesc* d, InrLayout& L) {
         L.out[l] = l + 1 == d->numLayers ? d->outDim : d->hidden;
         const uint32_t kt = l == 0 ? L.kt0 : d->hidden / 32, ot = (L.out[l] + 31) / 32;
         L.fragOff[l] = frag; L.biasOff[l] = bias; L.wOff[l] = w;
-        frag += ot * kt * 2 * (l == 0 ? 2 : 1);          // layer 0 stores a hi and a lo image
+        frag += ot * kt * 2 * (l == 0 ? 2 : 1);          // layer 0 stores hi and lo fragments side by side
         bias += ot * 32;
         w += L.in[l] * L.out[l];
     }
@@ -71,10 +76,10 @@ __global__ __launch_bounds__(256) void inr_pack_kernel(const float* __restrict__
     if (frag >= L.totalFrags) return;
     uint32_t l = 0;
     while (l + 1 < L.numLayers && frag >= L.fragOff[l + 1]) ++l;
-    const uint32_t kt = l == 0 ? L.kt0 : L.hidden / 32, ot = (L.out[l] + 31) / 32;
+    const uint32_t kt = l == 0 ? L.kt0 : L.hidden / 32;
     uint32_t f = frag - L.fragOff[l];
-    const bool lo = l == 0 && f >= ot * kt * 2;
-    if (lo) f -= ot * kt * 2;
+    bool lo = false;
+    if (l == 0) { lo = (f & 1u) != 0; f >>= 1; }
     const uint32_t s = f & 1u, t = (f >> 1) % kt, o = (f >> 1) / kt;
     const uint32_t r = lane & 31u, h = lane >> 5;
     uint16_t e[8];
@@ -127,24 +132,43 @@ __device__ __forceinline__ float input_feature(const InrArgs& a, uint32_t f, int
 }
 
 template <int HID, int KT0>
-__global__ __launch_bounds__(256) void inr_forward_kernel(const InrArgs a) {
-    constexpr int KT = HID / 32;
-    const uint32_t lane = threadIdx.x & 63u, r = lane & 31u, h = lane >> 5;
-    const int64_t waveId = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int64_t base = waveId * (kPT * 32);
-    if (base >= a.n) return;
+__global__ __launch_bounds__(512) void inr_forward_kernel(const InrArgs a) {
+    constexpr int KT = HID / 32;                         // k tiles of a hidden-wide input == out tiles of a hidden-wide output
+    constexpr int OTC = KT < 4 ? KT : 4;                 // out tiles per chunk (one barrier per chunk)
+    constexpr int F0 = KT0 * 4, FH = KT * 2;             // fragments per out tile: layer 0 (hi+lo) / other layers
+    constexpr int CH0 = OTC * F0, CHH = OTC * FH;        // fragments per chunk
+    constexpr int CHMAX = CH0 > CHH ? CH0 : CHH;
+    constexpr int PERW = (CHMAX + kInrWaves - 1) / kInrWaves;
+    __shared__ uint4 lds[2][CHMAX * 64];                 // 2 x <=64 KiB, the only LDS object (guide G17)
+
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, r = lane & 31u, h = lane >> 5;
+    const int64_t base = ((int64_t)blockIdx.x * kInrWaves + wave) * 32;
     const uint4* __restrict__ wp = a.wpack;
     const bool siren = a.kind == MRIRT_INR_SIREN || a.kind == 3u;
 
-    // ---- layer-0 B operands: this lane's point, features 16s + 8(j>>2) + 4h + (j&3) of k tile t --------
-    bf16x8 xin_hi[kPT][KT0][2], xin_lo[kPT][KT0][2];
-    int64_t pidx[kPT];
+    // ---- chunk streaming: LDS-DMA, one 1-KiB fragment per wave-instruction (lane-linear image) -----------
+    auto stage_issue = [&](uint32_t fragStart, int nfrag, int dstBuf) {
 #pragma unroll
-    for (int pt = 0; pt < kPT; ++pt) {
-        int64_t p = base + pt * 32 + r;
-        pidx[pt] = p;
-        const bool valid = p < a.n;
-        if (!valid) p = a.n - 1;                         // clamp: compute something, store nothing
+        for (int i = 0; i < PERW; ++i) {
+            const int f = (int)wave + i * kInrWaves;                 // wave-uniform
+            if (f < nfrag)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(wp + (size_t)(fragStart + f) * 64 + lane),
+                    (__attribute__((address_space(3))) void*)(&lds[dstBuf][f * 64]), 16, 0, 0);
+        }
+    };
+    auto frag_at = [&](int buf, int f) { return __builtin_bit_cast(bf16x8, lds[buf][f * 64 + lane]); };
+
+    uint32_t nextFrag = a.L.fragOff[0];
+    int buf = 0;
+    stage_issue(nextFrag, CH0, 0);
+    nextFrag += CH0;
+
+    // ---- layer-0 B operands: this lane's point, features 16s + 8(j>>2) + 4h + (j&3) of k tile t --------
+    bf16x8 xin_hi[KT0][2], xin_lo[KT0][2];
+    const int64_t pidx = base + r;
+    {
+        int64_t p = pidx < a.n ? pidx : a.n - 1;         // clamp: compute something, store nothing
         float c[3] = { 0.0f, 0.0f, 0.0f };
         if (a.volume) {                                  // model.py:124-128, fp64 then one rounding to fp32
             const uint32_t k = (uint32_t)(p % a.D), j = (uint32_t)((p / a.D) % a.W), i = (uint32_t)(p / ((int64_t)a.D * a.W));
@@ -163,125 +187,130 @@ __global__ __launch_bounds__(256) void inr_forward_kernel(const InrArgs a) {
                     const uint32_t f = 32 * t + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3);
                     const float v = input_feature(a, f, p, c);
                     const __bf16 hi = (__bf16)v;
-                    xin_hi[pt][t][s][j] = hi;
-                    xin_lo[pt][t][s][j] = (__bf16)(v - (float)hi);
+                    xin_hi[t][s][j] = hi;
+                    xin_lo[t][s][j] = (__bf16)(v - (float)hi);
                 }
     }
+    __syncthreads();                                     // chunk 0 is in LDS
 
-    bf16x8 Hc[kPT][KT][2];       // current layer's input, as B operands
-    bf16x8 Hn[kPT][KT][2];       // next layer's input, built out-tile by out-tile
+    bf16x8 Hc[KT][2];            // current layer's input, as B operands
+    bf16x8 Hn[KT][2];            // next layer's input, built out tile by out tile
 
-    auto activate = [&](const f32x16& acc, const float* __restrict__ bias, uint32_t o, bool first, int pt) {
+    // bias of out tile o for this lane half: rows 8g + 4h .. +3 (g = 0..3) = four aligned float4
+    auto load_bias = [&](const float* __restrict__ bias, int o, float4 b4[4]) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) b4[g] = *reinterpret_cast<const float4*>(bias + 32 * o + 8 * g + 4 * h);
+    };
+    auto activate = [&](const f32x16& acc, const float4 b4[4], int o, bool first) {
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int i = 8 * s + j;
-                const uint32_t row = 32 * o + (i & 3) + 8 * (i >> 2) + 4 * h;
+                const int i = 8 * s + j;                 // accumulator register i holds row (i&3) + 8(i>>2) + 4h
+                const float4 bq = b4[i >> 2];
+                const float b = (i & 3) == 0 ? bq.x : (i & 3) == 1 ? bq.y : (i & 3) == 2 ? bq.z : bq.w;
                 float x = acc[i];
-                if (siren) x = __builtin_sinf((first ? a.w0 * x : x) + bias[row]);     // neumors_inr.ipynb:1165-1178
-                else x = fmaxf(x + bias[row], 0.0f);                                    // model.py:46-48
-                Hn[pt][o][s][j] = (__bf16)x;
+                if (siren) {                             // neumors_inr.ipynb:1165-1178; v_sin_f32 takes revolutions
+                    x = (first ? a.w0 * x : x) + b;
+                    x = __builtin_amdgcn_sinf(x * 0.15915494309189535f);
+                } else {
+                    x = fmaxf(x + b, 0.0f);              // model.py:46-48
+                }
+                Hn[o][s][j] = (__bf16)x;
             }
     };
+    // the chunk prefetched during this chunk's compute becomes current (hipcc drains the LDS-DMA
+    // with vmcnt(0) at the barrier)
+    auto next_chunk = [&]() { __syncthreads(); buf ^= 1; };
 
-    // ---- layer 0: hi/lo split, three products ---------------------------------------------------------
+    // ---- layer 0: hi/lo split, three products per k step -------------------------------------------------
     {
-        const uint32_t imgLo = (HID / 32) * KT0 * 2;     // fragments in the hi image (out tiles x k tiles x 2)
         const float* __restrict__ b0 = a.bias + a.L.biasOff[0];
 #pragma unroll
-        for (int o = 0; o < KT; ++o) {                   // out tiles of a hidden-wide layer == KT
-            f32x16 acc[kPT];
+        for (int og = 0; og < KT / OTC; ++og) {
+            const int nfragNext = (og + 1 < KT / OTC) ? CH0 : (a.L.numLayers > 2 ? CHH : FH);   // layer 0 / layer 1 / head
+            stage_issue(nextFrag, nfragNext, buf ^ 1);
 #pragma unroll
-            for (int pt = 0; pt < kPT; ++pt) acc[pt] = (f32x16)(0.0f);
+            for (int oo = 0; oo < OTC; ++oo) {
+                const int o = og * OTC + oo;
+                float4 b4[4];
+                load_bias(b0, o, b4);
+                f32x16 acc = (f32x16)(0.0f);
 #pragma unroll
-            for (int t = 0; t < KT0; ++t)
+                for (int t = 0; t < KT0; ++t)
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const uint32_t fr = a.L.fragOff[0] + ((o * KT0 + t) * 2 + s);
-                    const bf16x8 whi = __builtin_bit_cast(bf16x8, wp[(size_t)fr * 64 + lane]);
-                    const bf16x8 wlo = __builtin_bit_cast(bf16x8, wp[(size_t)(fr + imgLo) * 64 + lane]);
-#pragma unroll
-                    for (int pt = 0; pt < kPT; ++pt) {
-                        acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo, xin_hi[pt][t][s], acc[pt], 0, 0, 0);
-                        acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi, xin_lo[pt][t][s], acc[pt], 0, 0, 0);
-                        acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi, xin_hi[pt][t][s], acc[pt], 0, 0, 0);
+                    for (int s = 0; s < 2; ++s) {
+                        const bf16x8 whi = frag_at(buf, oo * F0 + (t * 2 + s) * 2), wlo = frag_at(buf, oo * F0 + (t * 2 + s) * 2 + 1);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo, xin_hi[t][s], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi, xin_lo[t][s], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi, xin_hi[t][s], acc, 0, 0, 0);
                     }
-                }
-#pragma unroll
-            for (int pt = 0; pt < kPT; ++pt) activate(acc[pt], b0, o, true, pt);
+                activate(acc, b4, o, true);
+            }
+            next_chunk();
+            nextFrag += nfragNext;
         }
     }
 
     // ---- hidden layers 1 .. L-2 ----------------------------------------------------------------------------
     for (uint32_t l = 1; l + 1 < a.L.numLayers; ++l) {
 #pragma unroll
-        for (int pt = 0; pt < kPT; ++pt)
-#pragma unroll
-            for (int t = 0; t < KT; ++t) { Hc[pt][t][0] = Hn[pt][t][0]; Hc[pt][t][1] = Hn[pt][t][1]; }
-        const uint32_t f0 = a.L.fragOff[l];
+        for (int t = 0; t < KT; ++t) { Hc[t][0] = Hn[t][0]; Hc[t][1] = Hn[t][1]; }
         const float* __restrict__ bl = a.bias + a.L.biasOff[l];
+        const bool lastHidden = l + 2 == a.L.numLayers;
 #pragma unroll
-        for (int o = 0; o < KT; ++o) {
-            f32x16 acc[kPT];
+        for (int og = 0; og < KT / OTC; ++og) {
+            const int nfragNext = (og + 1 < KT / OTC || !lastHidden) ? CHH : FH;    // more hidden tiles, or the head
+            stage_issue(nextFrag, nfragNext, buf ^ 1);
 #pragma unroll
-            for (int pt = 0; pt < kPT; ++pt) acc[pt] = (f32x16)(0.0f);
+            for (int oo = 0; oo < OTC; ++oo) {
+                const int o = og * OTC + oo;
+                float4 b4[4];
+                load_bias(bl, o, b4);
+                f32x16 acc = (f32x16)(0.0f);
 #pragma unroll
-            for (int t = 0; t < KT; ++t)
+                for (int t = 0; t < KT; ++t)
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const bf16x8 wf = __builtin_bit_cast(bf16x8, wp[(size_t)(f0 + (o * KT + t) * 2 + s) * 64 + lane]);
-#pragma unroll
-                    for (int pt = 0; pt < kPT; ++pt)
-                        acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, Hc[pt][t][s], acc[pt], 0, 0, 0);
-                }
-#pragma unroll
-            for (int pt = 0; pt < kPT; ++pt) activate(acc[pt], bl, o, false, pt);
+                    for (int s = 0; s < 2; ++s)
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_at(buf, oo * FH + t * 2 + s), Hc[t][s], acc, 0, 0, 0);
+                activate(acc, b4, o, false);
+            }
+            next_chunk();
+            nextFrag += nfragNext;
         }
     }
 
     // ---- head: one out tile (outDim <= 16 rows used), linear ---------------------------------------------------
     {
-        const uint32_t l = a.L.numLayers - 1, f0 = a.L.fragOff[l];
-        const float* __restrict__ bl = a.bias + a.L.biasOff[l];
-        f32x16 acc[kPT];
-#pragma unroll
-        for (int pt = 0; pt < kPT; ++pt) acc[pt] = (f32x16)(0.0f);
+        const float* __restrict__ bl = a.bias + a.L.biasOff[a.L.numLayers - 1];
+        f32x16 acc = (f32x16)(0.0f);
 #pragma unroll
         for (int t = 0; t < KT; ++t)
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const bf16x8 wf = __builtin_bit_cast(bf16x8, wp[(size_t)(f0 + t * 2 + s) * 64 + lane]);
+            for (int s = 0; s < 2; ++s)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_at(buf, t * 2 + s), Hn[t][s], acc, 0, 0, 0);
+        float best = -INFINITY;
+        uint32_t bestc = 0xffffu;
 #pragma unroll
-                for (int pt = 0; pt < kPT; ++pt)
-                    acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, Hn[pt][t][s], acc[pt], 0, 0, 0);
+        for (int i = 0; i < 16; ++i) {
+            const uint32_t cls = (i & 3) + 8 * (i >> 2) + 4 * h;
+            if (cls < a.L.outDim) {
+                const float v = acc[i] + bl[cls];
+                if (a.logits && pidx < a.n) a.logits[pidx * a.L.outDim + cls] = v;
+                if (v > best || (v == best && cls < bestc)) { best = v; bestc = cls; }    // np.argmax: first maximum
             }
-#pragma unroll
-        for (int pt = 0; pt < kPT; ++pt) {
-            const int64_t p = pidx[pt];
-            float best = -INFINITY;
-            uint32_t bestc = 0xffffu;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const uint32_t cls = (i & 3) + 8 * (i >> 2) + 4 * h;
-                if (cls < a.L.outDim) {
-                    const float v = acc[pt][i] + bl[cls];
-                    if (a.logits && p < a.n) a.logits[p * a.L.outDim + cls] = v;
-                    if (v > best || (v == best && cls < bestc)) { best = v; bestc = cls; }    // np.argmax: first maximum
-                }
-            }
-            const float ob = __shfl_xor(best, 32);
-            const uint32_t oc = __shfl_xor(bestc, 32);
-            if (ob > best || (ob == best && oc < bestc)) { best = ob; bestc = oc; }
-            if (a.argmax && h == 0 && p < a.n) a.argmax[p] = (int16_t)bestc;
         }
+        const float ob = __shfl_xor(best, 32);
+        const uint32_t oc = __shfl_xor(bestc, 32);
+        if (ob > best || (ob == best && oc < bestc)) { best = ob; bestc = oc; }
+        if (a.argmax && h == 0 && pidx < a.n) a.argmax[pidx] = (int16_t)bestc;
     }
 }
 
 template <int HID>
 static int launch_inr_kt0(const InrArgs& a, hipStream_t s) {
-    const int64_t waves = (a.n + kPT * 32 - 1) / (kPT * 32);
-    const dim3 grid((uint32_t)((waves + 3) / 4)), block(256);
+    const int64_t groups = (a.n + kInrWaves * 32 - 1) / (kInrWaves * 32);
+    const dim3 grid((uint32_t)groups), block(kInrWaves * 64);
     if (a.L.kt0 == 1) hipLaunchKernelGGL((inr_forward_kernel<HID, 1>), grid, block, 0, s, a);
     else              hipLaunchKernelGGL((inr_forward_kernel<HID, 4>), grid, block, 0, s, a);
     MRIRT_HIP(hipGetLastError());
@@ -290,6 +319,7 @@ static int launch_inr_kt0(const InrArgs& a, hipStream_t s) {
 
 static int launch_inr(const InrArgs& a, hipStream_t s) {
     if (a.n <= 0) return MRIRT_OK;
+    if ((a.n + kInrWaves * 32 - 1) / (kInrWaves * 32) >= (1ll << 31)) return MRIRT_ERR_ARG;
     switch (a.L.hidden) {
         case 32: return launch_inr_kt0<32>(a, s);
         case 64: return launch_inr_kt0<64>(a, s);
