@@ -6,7 +6,9 @@ steps.  The N=1 workload is BASELINE config 3 ("C3"): one fp32 channel, perspect
 central-difference gradient + Blinn-Phong shading, early-ray termination (T <= 0.01), on the
 synthetic scene of SURVEY.md section 8(d) (``mrirt.synth``; intensityAlpha 16 so that
 termination fires).  A *step* is one rendered frame: ray generation, march, composite and the
-framebuffer store — and, for N > 1, the RCCL gather of the tiles to rank 0 plus de-tiling.
+framebuffer store — and, for N > 1, the RCCL all-gather of the tiles plus de-tiling on rank 0
+(issued asynchronously: frame k's exchange overlaps frame k+1's march; all K frames are fully
+exchanged and de-tiled before the clock stops).
 
 ``value`` = live samples of all ranks' frames / wall time.  Live samples (march-loop iterations
 that fetch the volume) are counted by the kernel itself in an untimed pass, so skipping work
@@ -133,17 +135,31 @@ def main():
 
     if world > 1:
         my_ext = tiles.shard_ext(ext, rank, world, a.tile)
-        n_local = tiles.local_tile_count(image, image, a.tile, rank, world)
-        local = torch.empty((n_local, a.tile, a.tile, 4), dtype=torch.float32, device=dev)
+        # double-buffered asynchronous exchange: frame k's all-gather overlaps frame k+1's march
+        ex = tiles.FrameExchange(image, image, a.tile, torch.float32, dev, depth=2, dst=0)
+        local = ex.local(0)
     else:
-        my_ext = ext
+        my_ext, ex = ext, None
         local = torch.empty((image, image, 4), dtype=torch.float32, device=dev)
 
-    def frame():
-        mrirt.render_brats(params, [grid], out=local, ext=my_ext)
-        if world > 1:
-            return tiles.gather_frame(local, image, image, a.tile)
-        return local
+    def run_frames(count, events=None):
+        """`count` frames back to back; every frame is fully exchanged and de-tiled on rank 0
+        before this returns (the caller synchronises)."""
+        for s in range(count):
+            slot = s % 2
+            if ex is not None and s >= 2:
+                ex.finish(slot)                       # frame s-2 used this slot: wait + de-tile it
+            buf = ex.local(slot) if ex is not None else local
+            if events is not None:
+                events[s][0].record()
+            mrirt.render_brats(params, [grid], out=buf, ext=my_ext)
+            if events is not None:
+                events[s][1].record()
+            if ex is not None:
+                ex.submit(slot)
+        if ex is not None:
+            for s in range(max(0, count - 2), count):
+                ex.finish(s % 2)
 
     # untimed: sample accounting by the kernel's own counters
     _, st = mrirt.render_brats(params, [grid], out=local, ext=my_ext, stats=True)
@@ -152,8 +168,7 @@ def main():
         dist.all_reduce(counts)
     live, shaded = int(counts[0]), int(counts[1])
 
-    for _ in range(a.warmup):
-        frame()
+    run_frames(a.warmup)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -161,14 +176,9 @@ def main():
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
     t0 = time.perf_counter()
-    for s in range(a.steps):
-        # HIP events on the launch stream bracket the march kernel alone (roofline);
-        # the wall clock brackets the whole step (value)
-        ev[s][0].record()
-        mrirt.render_brats(params, [grid], out=local, ext=my_ext)
-        ev[s][1].record()
-        if world > 1:
-            tiles.gather_frame(local, image, image, a.tile)
+    # HIP events on the launch stream bracket the march kernel alone (roofline);
+    # the wall clock brackets the whole K steps incl. every exchange and de-tiling (value)
+    run_frames(a.steps, ev)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

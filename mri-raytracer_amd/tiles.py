@@ -83,6 +83,48 @@ def gather_frame(local_tiles: torch.Tensor, width: int, height: int, tile: int =
     return None
 
 
+class FrameExchange:
+    """Double-buffered, asynchronous form of the exchange step for a frame loop.
+
+    ``local(i)`` is the compact tile buffer the march kernel writes for frame slot i (a view of a
+    buffer padded to rank 0's tile count); ``submit(i)`` starts the all-gather of that slot (the
+    collective runs on the backend's own stream and waits for the march kernel through stream
+    ordering, so the NEXT frame's march overlaps it); ``finish(i)`` waits for it and returns the
+    de-tiled frame (on ``dst`` only, None elsewhere).  Nothing is reduced, so one all-gather per
+    frame is the whole communication."""
+
+    def __init__(self, width: int, height: int, tile: int, dtype: torch.dtype, device, group=None,
+                 depth: int = 2, dst: Optional[int] = 0):
+        self.w, self.h, self.tile, self.group, self.dst = width, height, tile, group, dst
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.n_local = local_tile_count(width, height, tile, self.rank, self.world)
+        self.max_local = local_tile_count(width, height, tile, 0, self.world)
+        shape = (self.max_local, tile, tile, 4)
+        self._send = [torch.zeros(shape, dtype=dtype, device=device) for _ in range(depth)]
+        self._recv = [torch.empty((self.world * self.max_local, tile, tile, 4), dtype=dtype, device=device)
+                      for _ in range(depth)]
+        self._work = [None] * depth
+
+    def local(self, i: int) -> torch.Tensor:
+        return self._send[i][:self.n_local]
+
+    def submit(self, i: int) -> None:
+        if self.world == 1:
+            self._recv[i].copy_(self._send[i])
+            return
+        self._work[i] = dist.all_gather_into_tensor(self._recv[i], self._send[i], group=self.group, async_op=True)
+
+    def finish(self, i: int) -> Optional[torch.Tensor]:
+        if self._work[i] is not None:
+            self._work[i].wait()          # orders the current stream after the collective
+            self._work[i] = None
+        if self.dst is not None and self.rank != self.dst:
+            return None
+        g = self._recv[i].view(self.world, self.max_local, self.tile, self.tile, 4)
+        return assemble_frame(g, self.w, self.h, self.tile, self.world)
+
+
 def render_brats_sharded(params, intensities: Sequence, labels=None, preds=None, ext=None,
                          tile: int = DEFAULT_TILE, group=None, dst: int = 0, all_ranks: bool = False):
     """K1 across the process group: render this rank's tiles, then gather (see module docstring)."""

@@ -44,6 +44,20 @@ def _worker(rank, world, port, w, h, tile, all_ranks, q):
             ok = frame is not None and torch.equal(frame, torch.from_numpy(full))
         else:
             ok = frame is None
+        # the frame-loop form: double-buffered asynchronous exchange, 5 frames in flight order
+        ex = tiles.FrameExchange(w, h, tile, torch.float32, "cpu", depth=2, dst=0)
+        assert ex.n_local == n_local
+        got = []
+        for f in range(5):
+            slot = f % 2
+            if f >= 2:
+                got.append(ex.finish(slot))
+            ex.local(slot).copy_(local + float(f))
+            ex.submit(slot)
+        for f in range(3, 5):
+            got.append(ex.finish(f % 2))
+        for f, fr in enumerate(got):
+            ok = ok and ((fr is None) if rank != 0 else torch.equal(fr, torch.from_numpy(full) + float(f)))
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()
