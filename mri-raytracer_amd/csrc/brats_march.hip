@@ -45,7 +45,7 @@ struct K1Args {
     float ka, kd, ks, gradEps, ert;
     uint32_t specPow2;
     uint32_t half;           // 1: rgba16_float output
-    uint32_t soleChannel;    // index of the only enabled modality (pipelined kernel)
+    uint32_t nch, chan[4];   // the enabled modalities, compacted in ascending order (pipelined kernel)
     const void* vol[4];
     const uint32_t* labels;
     const uint32_t* preds;
@@ -187,8 +187,15 @@ __device__ __forceinline__ uint32_t sample_label(const uint32_t* __restrict__ bu
 // ---------------------------------------------------------------------------------------
 struct RayState { float C0, C1, C2, T; uint32_t nLive, nShaded; };
 
+// the two nearest-label gathers of a sample (issued with the intensity gathers, consumed in composite)
+struct Labels { uint32_t seg, pred; };
+__device__ __forceinline__ void fetch_labels(const K1Args& a, const Cell& s, Labels& l) {
+    l.seg = a.showSeg != 0 ? sample_label(a.labels, a.lab, s.q, a.hiLab) : 0u;      // :144
+    l.pred = a.showPred != 0 ? sample_label(a.preds, a.lab, s.q, a.hiLab) : 0u;     // :155
+}
+
 template <bool STRICT, bool SHADE>
-__device__ __forceinline__ void composite(const K1Args& a, const float rd[3], const Cell& s, float v, const float g[3],
+__device__ __forceinline__ void composite(const K1Args& a, const float rd[3], const Labels& lb, float v, const float g[3],
                                           RayState& r) {
     using Mm = M<STRICT>;
     // wSum (brats_rt.slang:123-130) is the same for every sample: summed on the host
@@ -221,7 +228,7 @@ __device__ __forceinline__ void composite(const K1Args& a, const float rd[3], co
         r.T *= (1.0f - alpha);
     }
     if (a.showSeg != 0) {                                            // :143-151
-        const uint32_t l = sample_label(a.labels, a.lab, s.q, a.hiLab);
+        const uint32_t l = lb.seg;
         if (l > 0 && l < 8) {
             const float alpha = 1.0f - Mm::exp(-a.lut[l][3] * a.stepSize);
             const float at = alpha * r.T;
@@ -230,7 +237,7 @@ __device__ __forceinline__ void composite(const K1Args& a, const float rd[3], co
         }
     }
     if (a.showPred != 0) {                                           // :154-162
-        const uint32_t l = sample_label(a.preds, a.lab, s.q, a.hiLab);
+        const uint32_t l = lb.pred;
         if (l > 0 && l < 8) {
             const float alpha = 1.0f - Mm::exp(-a.lut[l][3] * a.stepSize * 1.5f);
             const float at = alpha * r.T;
@@ -302,7 +309,9 @@ __global__ __launch_bounds__(256) void brats_march_kernel(const K1Args a) {
                         }
                     }
                 }
-                composite<STRICT, SHADE>(a, rd, s, v, g, r);
+                Labels lb;
+                fetch_labels(a, s, lb);
+                composite<STRICT, SHADE>(a, rd, lb, v, g, r);
                 t += a.stepSize;
             }
         }
@@ -311,13 +320,42 @@ __global__ __launch_bounds__(256) void brats_march_kernel(const K1Args a) {
 }
 
 // ---------------------------------------------------------------------------------------
-// Pipelined kernel: exactly one enabled modality.  Two stages ping-pong so that while stage A is
-// blended and composited, stage B's gathers (the NEXT step) are already in flight; the compiler
-// then waits with vmcnt(#gathers of one stage) instead of vmcnt(0).
+// Pipelined kernel: NCH enabled modalities (compacted on the host into a.chan[]).  Two stages
+// ping-pong so that while stage A is blended and composited, stage B's gathers (the NEXT step:
+// intensities of every enabled modality plus the label fetches) are already in flight; the
+// compiler then waits with vmcnt(#gathers of one stage) instead of vmcnt(0).
 // ---------------------------------------------------------------------------------------
-template <bool STRICT, int LAYOUT, bool SHADE>
+template <int LAYOUT, bool SHADE, int NCH>
+struct Stage {
+    Cell s;
+    Taps<LAYOUT, SHADE> taps[NCH];
+    Labels lb;
+    __device__ __forceinline__ void issue(const K1Args& a) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) taps[c].issue(a.vol[a.chan[c]], a.grid, s);
+        fetch_labels(a, s, lb);
+    }
+    template <bool STRICT>
+    __device__ __forceinline__ void consume(const K1Args& a, const float rd[3], RayState& r) const {
+        using Mm = M<STRICT>;
+        float v = 0.0f, g[3] = { 0.0f, 0.0f, 0.0f };
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {                      // ascending modality order, as the shader
+            float sv, gm[3];
+            taps[c].template eval<STRICT>(s, sv, gm);
+            const float w = a.weight[a.chan[c]];
+            v = Mm::mad(sv, w, v);
+            if constexpr (SHADE) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) g[k] = Mm::mad(gm[k], w, g[k]);
+            }
+        }
+        composite<STRICT, SHADE>(a, rd, lb, v, g, r);
+    }
+};
+
+template <bool STRICT, int LAYOUT, bool SHADE, int NCH>
 __global__ __launch_bounds__(256, 3) void brats_march_pipe_kernel(const K1Args a) {
-    using Mm = M<STRICT>;
     uint32_t px, py;
     int64_t oidx;
     const int kind = map_pixel(a.map, px, py, oidx);
@@ -325,37 +363,22 @@ __global__ __launch_bounds__(256, 3) void brats_march_pipe_kernel(const K1Args a
     if (kind == 1) {
         float ro[3], rd[3], t0, t1;
         if (setup_ray(a, px, py, ro, rd, t0, t1) && t0 < t1 && 1.0f > a.ert) {   // the while-condition at entry
-            const void* __restrict__ vol = a.vol[a.soleChannel];
-            const float w = a.weight[a.soleChannel];
             float t = t0;
-            Cell sA, sB;
-            Taps<LAYOUT, SHADE> A, B;
-            locate<STRICT>(a, ro, rd, t, sA);
-            A.issue(vol, a.grid, sA);
+            Stage<LAYOUT, SHADE, NCH> A, B;
+            locate<STRICT>(a, ro, rd, t, A.s);
+            A.issue(a);
             while (true) {
                 // invariant: stage A holds the sample at t, and (t < t1 && T > ert) holds
                 float tn = t + a.stepSize;
-                locate<STRICT>(a, ro, rd, tn, sB);
-                B.issue(vol, a.grid, sB);                             // speculative next step
-                {
-                    float sv, gm[3], g[3] = { 0.0f, 0.0f, 0.0f };
-                    A.template eval<STRICT>(sA, sv, gm);
-                    const float v = Mm::mad(sv, w, 0.0f);
-                    if constexpr (SHADE) { g[0] = Mm::mad(gm[0], w, 0.0f); g[1] = Mm::mad(gm[1], w, 0.0f); g[2] = Mm::mad(gm[2], w, 0.0f); }
-                    composite<STRICT, SHADE>(a, rd, sA, v, g, r);
-                }
+                locate<STRICT>(a, ro, rd, tn, B.s);
+                B.issue(a);                                           // speculative next step
+                A.template consume<STRICT>(a, rd, r);
                 t = tn;
                 if (!(t < t1 && r.T > a.ert)) break;
                 tn = t + a.stepSize;
-                locate<STRICT>(a, ro, rd, tn, sA);
-                A.issue(vol, a.grid, sA);
-                {
-                    float sv, gm[3], g[3] = { 0.0f, 0.0f, 0.0f };
-                    B.template eval<STRICT>(sB, sv, gm);
-                    const float v = Mm::mad(sv, w, 0.0f);
-                    if constexpr (SHADE) { g[0] = Mm::mad(gm[0], w, 0.0f); g[1] = Mm::mad(gm[1], w, 0.0f); g[2] = Mm::mad(gm[2], w, 0.0f); }
-                    composite<STRICT, SHADE>(a, rd, sB, v, g, r);
-                }
+                locate<STRICT>(a, ro, rd, tn, A.s);
+                A.issue(a);
+                B.template consume<STRICT>(a, rd, r);
                 t = tn;
                 if (!(t < t1 && r.T > a.ert)) break;
             }
@@ -364,16 +387,31 @@ __global__ __launch_bounds__(256, 3) void brats_march_pipe_kernel(const K1Args a
     finish(a, kind, oidx, r);
 }
 
+template <bool STRICT, int LAYOUT, bool SHADE, int NCH>
+static int launch_pipe(const K1Args& a, hipStream_t s) {
+    const dim3 grid(a.map.chunk * kXcds), block(a.map.blockPx == 8 ? 64 : 256);
+    hipLaunchKernelGGL((brats_march_pipe_kernel<STRICT, LAYOUT, SHADE, NCH>), grid, block, 0, s, a);
+    MRIRT_HIP(hipGetLastError());
+    return MRIRT_OK;
+}
+
 template <bool STRICT, int LAYOUT, bool SHADE>
 static int launch(const K1Args& a, bool pipe, hipStream_t s) {
-    const dim3 grid(a.map.chunk * kXcds), block(a.map.blockPx == 8 ? 64 : 256);
-    if constexpr (LAYOUT >= 2) {
+    if constexpr (LAYOUT == 2) {                      // VG: 8 float4 per modality per stage -> one modality
+        if (pipe && a.nch == 1) return launch_pipe<STRICT, 2, SHADE, 1>(a, s);
+    }
+    if constexpr (LAYOUT == 3) {                      // QUAD: 2 float4 per modality per stage -> up to four
         if (pipe) {
-            hipLaunchKernelGGL((brats_march_pipe_kernel<STRICT, LAYOUT, SHADE>), grid, block, 0, s, a);
-            MRIRT_HIP(hipGetLastError());
-            return MRIRT_OK;
+            switch (a.nch) {
+                case 1: return launch_pipe<STRICT, 3, false, 1>(a, s);
+                case 2: return launch_pipe<STRICT, 3, false, 2>(a, s);
+                case 3: return launch_pipe<STRICT, 3, false, 3>(a, s);
+                case 4: return launch_pipe<STRICT, 3, false, 4>(a, s);
+                default: break;
+            }
         }
     }
+    const dim3 grid(a.map.chunk * kXcds), block(a.map.blockPx == 8 ? 64 : 256);
     hipLaunchKernelGGL((brats_march_kernel<STRICT, LAYOUT, SHADE>), grid, block, 0, s, a);
     MRIRT_HIP(hipGetLastError());
     return MRIRT_OK;
@@ -433,12 +471,13 @@ extern "C" int mrirt_render_brats_ex(const MrirtBratsParams* p, const MrirtRende
     a.stepSize = p->stepSize; a.nearT = p->nearT; a.farT = p->farT;
     float wSum = 0.0f;
     uint32_t nEnabled = 0;
-    a.soleChannel = 0;
+    a.nch = 0;
+    for (int m = 0; m < 4; ++m) a.chan[m] = 0;
     for (int m = 0; m < 4; ++m) {
         a.enabled[m] = p->volEnabled[m];
         a.weight[m] = p->volWeight[m];
         a.vol[m] = vol[m];
-        if (p->volEnabled[m] != 0) { wSum += p->volWeight[m]; a.soleChannel = (uint32_t)m; ++nEnabled; }   // shader's order
+        if (p->volEnabled[m] != 0) { wSum += p->volWeight[m]; a.chan[a.nch++] = (uint32_t)m; ++nEnabled; }   // shader's order
     }
     a.wsum = make_udiv(wSum);
     a.wwDiv = make_udiv(p->ww);
@@ -458,7 +497,7 @@ extern "C" int mrirt_render_brats_ex(const MrirtBratsParams* p, const MrirtRende
     a.stats = stats_dev;
     if (a.map.numBlocks == 0) return MRIRT_OK;   // a rank that owns no tile
 
-    const bool pipe = nEnabled == 1 && !(variant & 4u);
+    const bool pipe = nEnabled >= 1 && !(variant & 4u);
     hipStream_t s = static_cast<hipStream_t>(stream);
     return math == MRIRT_MATH_STRICT ? launch_layout<true>(a, layout, shade, pipe, s)
                                      : launch_layout<false>(a, layout, shade, pipe, s);

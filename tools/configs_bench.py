@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""BASELINE configs C1 (CPU oracle, K2 fp32 ortho), C2 (K1 reference semantics: 4 modalities + seg
+overlay, 256^3, 512^2, 256 steps) and C3 on one GPU; prints one row per run."""
+import os, sys, time, json
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, mrirt
+from mrirt import synth
+from oracle import oracle_c, oracle_np
+
+def timeit(fn, rounds=7):
+    ts = []
+    for _ in range(rounds):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
+    return float(np.median(ts))
+
+rows = []
+# ---- C1: 128^3 fp32, 256x256 orthographic, 64 steps: K2 loop, CPU oracle (plumbing config) + GPU beside it
+f = synth.synth_volume(128)
+p = synth.volume_scene(128, 256, 64)
+ext = dict(cameraMode=1, orthoHalfHeight=1.1)
+t = time.perf_counter(); ref, aux = oracle_c.volume_cs(p, f, mode="f32", ext=ext, return_aux=True); dt_c = time.perf_counter() - t
+t = time.perf_counter(); refn = oracle_np.volume_cs(p, f, mode="f32", ext=ext); dt_np = time.perf_counter() - t
+assert np.array_equal(ref, refn)
+g = torch.from_numpy(f).cuda()
+img, st = mrirt.render_volume_u8(p, g, mode="f32", ext=ext, stats=True)
+ms = timeit(lambda: mrirt.render_volume_u8(p, g, mode="f32", ext=ext))
+rows.append(("C1 128^3 256^2 64 ortho K2-f32", f"CPU-np {dt_np*1e3:.0f} ms ({aux['live_samples']/dt_np/1e6:.1f} Ms/s 1 thr), CPU-omp {dt_c*1e3:.1f} ms ({aux['live_samples']/dt_c/1e6:.0f} Ms/s {os.cpu_count()} thr)",
+             ms, aux["live_samples"], float(np.abs(img.cpu().numpy() - ref).max())))
+# ---- C2: 256^3 BraTS-shaped (4 channels + labels), 512^2 perspective, 256 steps
+n = 256
+vols = [synth.synth_volume(n, 1234 + m, phase=0.3 * m) for m in range(4)]
+lab = synth.synth_labels(n)
+p2 = synth.brats_scene(n, 512, 256, channels=4, show_seg=True, intensity_alpha=0.4)
+t = time.perf_counter(); ref2, aux2 = oracle_c.brats_main(p2, vols, lab, None, return_aux=True); dt2 = time.perf_counter() - t
+for layout in ("linear", "brick", "quad"):
+    gv = [mrirt.upload_grid(v, (n, n, n), layout) for v in vols]
+    gl = mrirt.upload_grid(lab, (n, n, n), "linear" if layout == "linear" else "brick")
+    for math_ in ("strict", "fast"):
+        e = dict(math=math_)
+        img = mrirt.render_brats(p2, gv, gl, ext=e)
+        err = float(np.abs(img.cpu().numpy() - ref2).max())
+        ms = timeit(lambda: mrirt.render_brats(p2, gv, gl, ext=e))
+        rows.append((f"C2 256^3x4ch+seg 512^2 256 {layout} {math_}", f"CPU-omp {dt2*1e3:.0f} ms ({aux2['live_samples']/dt2/1e6:.0f} Ms/s)", ms, aux2["live_samples"], err))
+    del gv
+# single-channel variant of C2 for the GB/s headline
+p2s = synth.brats_scene(n, 512, 256, channels=1, intensity_alpha=0.4)
+gq = mrirt.upload_grid(vols[0], (n, n, n), "quad")
+_, sts = mrirt.render_brats(p2s, [gq], stats=True)
+ms = timeit(lambda: mrirt.render_brats(p2s, [gq]))
+rows.append(("C2-1ch 256^3 512^2 256 quad strict", "", ms, sts["live_samples"], 0.0))
+print(f"{'config':48s} {'GPU ms':>8s} {'live Ms':>9s} {'Gsamp/s':>8s} {'max|err|':>9s}  cpu")
+for name, cpu, ms, live, err in rows:
+    print(f"{name:48s} {ms:8.3f} {live/1e6:9.2f} {live/ms/1e6:8.2f} {err:9.2e}  {cpu}")
