@@ -124,6 +124,27 @@ int mrirt_render_brats_ex(const MrirtBratsParams* params, const MrirtRenderExt* 
 
 /* Host CPU twin? No: the product has no CPU fallback.  The CPU restatement lives in oracle/. */
 
+/* Per-sample INR query along the rays (build-defined, BASELINE config 5): the label
+ * of the prediction overlay (brats_rt.slang:154-162) comes from an MLP evaluated AT each sample
+ * instead of sampleLabel(gPreds).  Three device passes around mrirt_inr_forward:
+ *   1. mrirt_brats_sample_counts: counts[y*W + x] = steps ray (x,y) takes in [t0,t1) (no ERT: the
+ *      classes are needed to know T).  Caller: exclusive prefix sum -> offsets (int64), total.
+ *   2. mrirt_brats_emit_samples: MLP inputs of sample k of ray p at row offsets[p] + k:
+ *      coords[row][3] = 2*clamp(pIdx,0,dim-1)/(dim-1) - 1 (== predict_volume's coordinate at lattice
+ *      points, inr/inr/model.py:124-128), feats[row][4] = the four trilinear samples z-scored as
+ *      (v - zmu[m]) / zsigma[m] (inr/viewer/brats_viewer.py:281-287).  All four grids must be bound.
+ *      Caller: mrirt_inr_forward(desc, coords, feats, total, NULL, classes).
+ *   3. mrirt_render_brats_stream: K1 as mrirt_render_brats_ex, the prediction label of sample k of
+ *      ray p read from classes[offsets[p] + k] (requires params->showPred != 0; whole-frame only). */
+int mrirt_brats_sample_counts(const MrirtBratsParams* params, const MrirtRenderExt* ext, uint32_t* counts, void* stream);
+int mrirt_brats_emit_samples(const MrirtBratsParams* params, const MrirtRenderExt* ext, const void* const vol[4],
+                             const float zmu[4], const float zsigma[4], const int64_t* offsets,
+                             float* coords, float* feats, void* stream);
+int mrirt_render_brats_stream(const MrirtBratsParams* params, const MrirtRenderExt* ext,
+                              const void* const vol[4], const void* labels,
+                              const int16_t* classes, const int64_t* offsets,
+                              void* out_rgba, int64_t pitch_px, uint64_t* stats_dev, void* stream);
+
 /* ------------------------------------------------------------------------------------ */
 /* Brick layout conversion (load-time; replaces create_buffer + copy_from_numpy,         */
 /* inr/viewer/brats_viewer.py:219-230)                                                   */

@@ -20,7 +20,8 @@ HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-s
 
 # every extern "C" symbol include/mrirt.h declares
 ABI_SYMBOLS = [
-    "mrirt_render_brats", "mrirt_render_brats_ex", "mrirt_brick_elems", "mrirt_brick_grid",
+    "mrirt_render_brats", "mrirt_render_brats_ex", "mrirt_brats_sample_counts", "mrirt_brats_emit_samples",
+    "mrirt_render_brats_stream", "mrirt_brick_elems", "mrirt_brick_grid",
     "mrirt_unbrick_grid", "mrirt_vec4_elems", "mrirt_build_vec4_grid", "mrirt_render_volume", "mrirt_render_sdf", "mrirt_tiles_for_rank",
     "mrirt_detile", "mrirt_inr_pack_bytes", "mrirt_inr_pack_weights", "mrirt_inr_forward",
     "mrirt_inr_predict_volume", "mrirt_abi_version", "mrirt_status_string", "mrirt_last_hip_error",
@@ -144,6 +145,13 @@ def lib() -> C.CDLL:
     vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int
     l.mrirt_render_brats.argtypes = [C.POINTER(BratsParams), C.POINTER(vp), vp, vp, vp, i64, vp]
     l.mrirt_render_brats_ex.argtypes = [C.POINTER(BratsParams), C.POINTER(RenderExt), C.POINTER(vp), vp, vp, vp, i64, vp, vp]
+    l.mrirt_brats_sample_counts.argtypes = [C.POINTER(BratsParams), C.POINTER(RenderExt), vp, vp]
+    l.mrirt_brats_emit_samples.argtypes = [C.POINTER(BratsParams), C.POINTER(RenderExt), C.POINTER(vp),
+                                           C.POINTER(f32), C.POINTER(f32), vp, vp, vp, vp]
+    l.mrirt_render_brats_stream.argtypes = [C.POINTER(BratsParams), C.POINTER(RenderExt), C.POINTER(vp), vp, vp, vp,
+                                            vp, i64, vp, vp]
+    for fn in ("mrirt_brats_sample_counts", "mrirt_brats_emit_samples", "mrirt_render_brats_stream"):
+        getattr(l, fn).restype = i32
     l.mrirt_brick_elems.argtypes = [C.POINTER(u32)]
     l.mrirt_brick_elems.restype = i64
     l.mrirt_brick_grid.argtypes = [vp, vp, C.POINTER(u32), u32, vp]

@@ -49,6 +49,8 @@ struct K1Args {
     const void* vol[4];
     const uint32_t* labels;
     const uint32_t* preds;
+    const int16_t* classStream;   // C5: prediction label of sample k of ray p at classStream[rayOffsets[p] + k]
+    const int64_t* rayOffsets;
     void* out;
     uint64_t* stats;
 };
@@ -189,9 +191,11 @@ struct RayState { float C0, C1, C2, T; uint32_t nLive, nShaded; };
 
 // the two nearest-label gathers of a sample (issued with the intensity gathers, consumed in composite)
 struct Labels { uint32_t seg, pred; };
-__device__ __forceinline__ void fetch_labels(const K1Args& a, const Cell& s, Labels& l) {
+__device__ __forceinline__ void fetch_labels(const K1Args& a, const Cell& s, Labels& l, int64_t streamRow = 0) {
     l.seg = a.showSeg != 0 ? sample_label(a.labels, a.lab, s.q, a.hiLab) : 0u;      // :144
-    l.pred = a.showPred != 0 ? sample_label(a.preds, a.lab, s.q, a.hiLab) : 0u;     // :155
+    if (a.showPred == 0) l.pred = 0u;
+    else if (a.classStream != nullptr) l.pred = (uint32_t)(uint16_t)a.classStream[streamRow];   // C5
+    else l.pred = sample_label(a.preds, a.lab, s.q, a.hiLab);                       // :155
 }
 
 template <bool STRICT, bool SHADE>
@@ -291,6 +295,7 @@ __global__ __launch_bounds__(256) void brats_march_kernel(const K1Args a) {
         float ro[3], rd[3], t0, t1;
         if (setup_ray(a, px, py, ro, rd, t0, t1)) {
             float t = t0;
+            const int64_t streamBase = a.classStream != nullptr ? a.rayOffsets[(int64_t)py * a.map.width + px] : 0;
             while (t < t1 && r.T > a.ert) {
                 Cell s;
                 locate<STRICT>(a, ro, rd, t, s);
@@ -310,7 +315,7 @@ __global__ __launch_bounds__(256) void brats_march_kernel(const K1Args a) {
                     }
                 }
                 Labels lb;
-                fetch_labels(a, s, lb);
+                fetch_labels(a, s, lb, streamBase + r.nLive);       // nLive == index of this step along the ray
                 composite<STRICT, SHADE>(a, rd, lb, v, g, r);
                 t += a.stepSize;
             }
@@ -428,17 +433,64 @@ static int launch_layout(const K1Args& a, uint32_t layout, bool shade, bool pipe
     }
 }
 
-}  // namespace mrirt
+// ---------------------------------------------------------------------------------------
+// C5 (per-sample INR query): sample counting and MLP-input emission.  Build-defined extension.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sample_count_kernel(const K1Args a, uint32_t* __restrict__ counts) {
+    uint32_t px, py;
+    int64_t oidx;
+    if (map_pixel(a.map, px, py, oidx) != 1) return;
+    float ro[3], rd[3], t0, t1;
+    uint32_t n = 0;
+    if (setup_ray(a, px, py, ro, rd, t0, t1))
+        for (float t = t0; t < t1; t += a.stepSize) ++n;            // the same fp32 accumulation as the march
+    counts[(int64_t)py * a.map.width + px] = n;
+}
 
-using namespace mrirt;
+struct EmitArgs {
+    UDiv zsigma[4];
+    float zmu[4];
+    double dimM1[3];             // dim - 1 (fp64 divide: the same expression as predict_volume)
+    const int64_t* offsets;
+    float* coords;
+    float4* feats;
+};
 
-// kernelVariant toggles (experiments; 0 = library default):
-//   bit 0: row-major instead of Morton lane order      bit 1: 256-thread instead of 64-thread workgroups
-//   bit 2: no software pipelining
-extern "C" int mrirt_render_brats_ex(const MrirtBratsParams* p, const MrirtRenderExt* ext,
-                                     const void* const vol[4], const void* labels, const void* preds,
-                                     void* out_rgba, int64_t pitch_px, uint64_t* stats_dev, void* stream) {
-    if (!p || !out_rgba || !vol) return MRIRT_ERR_NULL;
+template <bool STRICT, int LAYOUT>
+__global__ __launch_bounds__(256) void emit_samples_kernel(const K1Args a, const EmitArgs e) {
+    using Mm = M<STRICT>;
+    uint32_t px, py;
+    int64_t oidx;
+    if (map_pixel(a.map, px, py, oidx) != 1) return;
+    float ro[3], rd[3], t0, t1;
+    if (!setup_ray(a, px, py, ro, rd, t0, t1)) return;
+    int64_t row = e.offsets[(int64_t)py * a.map.width + px];
+    for (float t = t0; t < t1; t += a.stepSize, ++row) {
+        Cell s;
+        locate<STRICT>(a, ro, rd, t, s);
+        float z[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            Taps<LAYOUT, false> taps;
+            float v;
+            taps.issue(a.vol[m], a.grid, s);
+            taps.template eval<STRICT>(s, v, nullptr);
+            z[m] = STRICT ? Mm::divu(v - e.zmu[m], e.zsigma[m]) : (v - e.zmu[m]) * e.zsigma[m].r;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k)      // fp64, one rounding: predict_volume's coordinate at lattice points
+            e.coords[row * 3 + k] = (float)(((double)clampf(s.q[k], 0.0f, a.hiLab[k]) / e.dimM1[k]) * 2.0 - 1.0);
+        e.feats[row] = make_float4(z[0], z[1], z[2], z[3]);
+    }
+}
+
+struct Prepared { uint32_t layout, math; bool shade, pipe; };
+
+// validate + fill the kernel arguments shared by every K1 entry point
+static int prepare(const MrirtBratsParams* p, const MrirtRenderExt* ext, const void* const vol[4],
+                   const void* labels, const void* preds, bool needVolumes, int64_t pitch_px,
+                   K1Args& a, Prepared& cfg) {
+    if (!p || (needVolumes && !vol)) return MRIRT_ERR_NULL;
     for (int k = 0; k < 3; ++k) if (p->dims[k] < 2) return MRIRT_ERR_DIMS;
     const uint32_t layout = ext ? ext->layout : (uint32_t)MRIRT_LAYOUT_LINEAR;
     const uint32_t labLayout = ext ? ext->labelLayout : (uint32_t)MRIRT_LAYOUT_LINEAR;
@@ -449,10 +501,10 @@ extern "C" int mrirt_render_brats_ex(const MrirtBratsParams* p, const MrirtRende
         return MRIRT_ERR_LAYOUT;
     if (mrirt_brick_elems(p->dims) >= (int64_t)1 << 32 || mrirt_vec4_elems(p->dims) >= (int64_t)1 << 32)
         return MRIRT_ERR_DIMS;                                           // 32-bit element offsets
-    for (int m = 0; m < 4; ++m) if (p->volEnabled[m] != 0 && !vol[m]) return MRIRT_ERR_NULL;
-    if ((p->showSeg != 0 && !labels) || (p->showPred != 0 && !preds)) return MRIRT_ERR_NULL;
-
-    K1Args a;
+    if (needVolumes) {
+        for (int m = 0; m < 4; ++m) if (p->volEnabled[m] != 0 && !vol[m]) return MRIRT_ERR_NULL;
+        if (p->showSeg != 0 && !labels) return MRIRT_ERR_NULL;
+    }
     fill_camera(a.cam, p->eye, p->U, p->V, p->W, p->fovY, p->imageSize[0], p->imageSize[1], ext, false);
     int rc = fill_pixel_map(a.map, p->imageSize[0], p->imageSize[1], pitch_px, ext,
                             (variant & 2u) ? 16u : 8u, (variant & 1u) ? 0u : 1u);
@@ -470,14 +522,13 @@ extern "C" int mrirt_render_brats_ex(const MrirtBratsParams* p, const MrirtRende
     }
     a.stepSize = p->stepSize; a.nearT = p->nearT; a.farT = p->farT;
     float wSum = 0.0f;
-    uint32_t nEnabled = 0;
     a.nch = 0;
     for (int m = 0; m < 4; ++m) a.chan[m] = 0;
     for (int m = 0; m < 4; ++m) {
         a.enabled[m] = p->volEnabled[m];
         a.weight[m] = p->volWeight[m];
-        a.vol[m] = vol[m];
-        if (p->volEnabled[m] != 0) { wSum += p->volWeight[m]; a.chan[a.nch++] = (uint32_t)m; ++nEnabled; }   // shader's order
+        a.vol[m] = vol ? vol[m] : nullptr;
+        if (p->volEnabled[m] != 0) { wSum += p->volWeight[m]; a.chan[a.nch++] = (uint32_t)m; }   // shader's order
     }
     a.wsum = make_udiv(wSum);
     a.wwDiv = make_udiv(p->ww);
@@ -485,7 +536,6 @@ extern "C" int mrirt_render_brats_ex(const MrirtBratsParams* p, const MrirtRende
     a.intensityAlpha = p->intensityAlpha; a.gamma = p->gamma;
     a.showSeg = p->showSeg; a.showPred = p->showPred;
     for (int i = 0; i < 8; ++i) for (int j = 0; j < 4; ++j) a.lut[i][j] = p->lutColorAlpha[i][j];
-    const bool shade = ext && ext->shadeMode != 0;
     a.ka = ext ? ext->ka : 0.0f; a.kd = ext ? ext->kd : 0.0f; a.ks = ext ? ext->ks : 0.0f;
     a.gradEps = ext ? ext->gradEps : 0.0f;
     a.specPow2 = ext ? ext->specPow2 : 0u;
@@ -493,14 +543,36 @@ extern "C" int mrirt_render_brats_ex(const MrirtBratsParams* p, const MrirtRende
     a.half = fmt == MRIRT_OUT_RGBA16F ? 1u : 0u;
     a.labels = static_cast<const uint32_t*>(labels);
     a.preds = static_cast<const uint32_t*>(preds);
+    a.classStream = nullptr; a.rayOffsets = nullptr;
+    a.out = nullptr; a.stats = nullptr;
+    cfg.layout = layout; cfg.math = math;
+    cfg.shade = ext && ext->shadeMode != 0;
+    cfg.pipe = a.nch >= 1 && !(variant & 4u);
+    return MRIRT_OK;
+}
+
+}  // namespace mrirt
+
+using namespace mrirt;
+
+// kernelVariant toggles (experiments; 0 = library default):
+//   bit 0: row-major instead of Morton lane order      bit 1: 256-thread instead of 64-thread workgroups
+//   bit 2: no software pipelining
+extern "C" int mrirt_render_brats_ex(const MrirtBratsParams* p, const MrirtRenderExt* ext,
+                                     const void* const vol[4], const void* labels, const void* preds,
+                                     void* out_rgba, int64_t pitch_px, uint64_t* stats_dev, void* stream) {
+    if (!out_rgba) return MRIRT_ERR_NULL;
+    K1Args a;
+    Prepared cfg;
+    int rc = prepare(p, ext, vol, labels, preds, true, pitch_px, a, cfg);
+    if (rc != MRIRT_OK) return rc;
+    if (p->showPred != 0 && !preds) return MRIRT_ERR_NULL;
     a.out = out_rgba;
     a.stats = stats_dev;
     if (a.map.numBlocks == 0) return MRIRT_OK;   // a rank that owns no tile
-
-    const bool pipe = nEnabled >= 1 && !(variant & 4u);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    return math == MRIRT_MATH_STRICT ? launch_layout<true>(a, layout, shade, pipe, s)
-                                     : launch_layout<false>(a, layout, shade, pipe, s);
+    return cfg.math == MRIRT_MATH_STRICT ? launch_layout<true>(a, cfg.layout, cfg.shade, cfg.pipe, s)
+                                         : launch_layout<false>(a, cfg.layout, cfg.shade, cfg.pipe, s);
 }
 
 extern "C" int mrirt_render_brats(const MrirtBratsParams* params, const float* const vol[4],
@@ -509,4 +581,66 @@ extern "C" int mrirt_render_brats(const MrirtBratsParams* params, const float* c
     if (!vol) return MRIRT_ERR_NULL;
     const void* v[4] = { vol[0], vol[1], vol[2], vol[3] };
     return mrirt_render_brats_ex(params, nullptr, v, labels, preds, out_rgba, pitch_px, nullptr, stream);
+}
+
+extern "C" int mrirt_render_brats_stream(const MrirtBratsParams* p, const MrirtRenderExt* ext,
+                                         const void* const vol[4], const void* labels,
+                                         const int16_t* classes, const int64_t* offsets,
+                                         void* out_rgba, int64_t pitch_px, uint64_t* stats_dev, void* stream) {
+    if (!out_rgba || !classes || !offsets) return MRIRT_ERR_NULL;
+    if (ext && ext->tileWorld > 1) return MRIRT_ERR_ARG;         // whole-frame only
+    K1Args a;
+    Prepared cfg;
+    int rc = prepare(p, ext, vol, labels, nullptr, true, pitch_px, a, cfg);
+    if (rc != MRIRT_OK) return rc;
+    if (p->showPred == 0) return MRIRT_ERR_ARG;
+    a.classStream = classes; a.rayOffsets = offsets;
+    a.out = out_rgba; a.stats = stats_dev;
+    hipStream_t s = static_cast<hipStream_t>(stream);            // the streamed label lives in the general kernel
+    return cfg.math == MRIRT_MATH_STRICT ? launch_layout<true>(a, cfg.layout, cfg.shade, false, s)
+                                         : launch_layout<false>(a, cfg.layout, cfg.shade, false, s);
+}
+
+extern "C" int mrirt_brats_sample_counts(const MrirtBratsParams* p, const MrirtRenderExt* ext, uint32_t* counts, void* stream) {
+    if (!counts) return MRIRT_ERR_NULL;
+    if (ext && ext->tileWorld > 1) return MRIRT_ERR_ARG;
+    K1Args a;
+    Prepared cfg;
+    int rc = prepare(p, ext, nullptr, nullptr, nullptr, false, p ? p->imageSize[0] : 0, a, cfg);
+    if (rc != MRIRT_OK) return rc;
+    hipLaunchKernelGGL(sample_count_kernel, dim3(a.map.chunk * kXcds), dim3(a.map.blockPx == 8 ? 64 : 256), 0,
+                       static_cast<hipStream_t>(stream), a, counts);
+    MRIRT_HIP(hipGetLastError());
+    return MRIRT_OK;
+}
+
+template <bool STRICT>
+static int launch_emit(const K1Args& a, const EmitArgs& e, uint32_t layout, hipStream_t s) {
+    const dim3 grid(a.map.chunk * kXcds), block(a.map.blockPx == 8 ? 64 : 256);
+    switch (layout) {
+        case MRIRT_LAYOUT_LINEAR: hipLaunchKernelGGL((emit_samples_kernel<STRICT, 0>), grid, block, 0, s, a, e); break;
+        case MRIRT_LAYOUT_BRICK:  hipLaunchKernelGGL((emit_samples_kernel<STRICT, 1>), grid, block, 0, s, a, e); break;
+        case MRIRT_LAYOUT_VG:     hipLaunchKernelGGL((emit_samples_kernel<STRICT, 2>), grid, block, 0, s, a, e); break;
+        default:                  hipLaunchKernelGGL((emit_samples_kernel<STRICT, 3>), grid, block, 0, s, a, e); break;
+    }
+    MRIRT_HIP(hipGetLastError());
+    return MRIRT_OK;
+}
+
+extern "C" int mrirt_brats_emit_samples(const MrirtBratsParams* p, const MrirtRenderExt* ext, const void* const vol[4],
+                                        const float zmu[4], const float zsigma[4], const int64_t* offsets,
+                                        float* coords, float* feats, void* stream) {
+    if (!vol || !zmu || !zsigma || !offsets || !coords || !feats) return MRIRT_ERR_NULL;
+    for (int m = 0; m < 4; ++m) if (!vol[m]) return MRIRT_ERR_NULL;          // the MLP reads all four modalities
+    if (ext && ext->tileWorld > 1) return MRIRT_ERR_ARG;
+    K1Args a;
+    Prepared cfg;
+    int rc = prepare(p, ext, vol, nullptr, nullptr, false, p ? p->imageSize[0] : 0, a, cfg);
+    if (rc != MRIRT_OK) return rc;
+    EmitArgs e;
+    for (int m = 0; m < 4; ++m) { e.zmu[m] = zmu[m]; e.zsigma[m] = make_udiv(zsigma[m]); }
+    for (int k = 0; k < 3; ++k) e.dimM1[k] = (double)(p->dims[k] - 1);
+    e.offsets = offsets; e.coords = coords; e.feats = reinterpret_cast<float4*>(feats);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return cfg.math == MRIRT_MATH_STRICT ? launch_emit<true>(a, e, cfg.layout, s) : launch_emit<false>(a, e, cfg.layout, s);
 }

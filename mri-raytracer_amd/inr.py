@@ -189,6 +189,55 @@ def predict_volume(params, case_data: Dict[str, Any], fourier_freqs: int, chunk:
     return pred, case_data.get("seg")
 
 
+def render_brats_inr(params, intensities, net: PackedMLP, zmu, zsigma, labels=None, out=None, ext=None,
+                     return_aux: bool = False):
+    """BASELINE config 5 (build-defined): K1 with the prediction overlay's label taken
+    from the MLP evaluated AT every march sample (normalised sample coordinates + the four
+    trilinear-sampled, z-scored modalities) instead of ``sampleLabel(gPreds)``.
+
+    Three device passes around the MFMA kernel (csrc/brats_march.hip, csrc/inr_mlp.hip):
+    count the samples of every ray, emit the MLP inputs of all of them, classify them in one
+    batched ``mrirt_inr_forward``, then composite with the class stream.  ``net`` must be a
+    Fourier/ReLU network over 4 modalities (``pack_mlp(params, KIND_FOURIER_RELU, K, 4)``);
+    ``zmu``/``zsigma`` are the per-modality z-score constants (brats_viewer.py:281-287).
+    """
+    from .render import _alloc_out, _bind_brats
+    dev = _require_gpu()
+    if int(params["showPred"]) == 0:
+        raise ValueError("render_brats_inr draws the prediction overlay: set gParams.showPred")
+    if net.desc.kind != KIND_FOURIER_RELU or net.desc.numMods != 4:
+        raise ValueError("render_brats_inr needs a Fourier/ReLU network over 4 modalities")
+    P, E, vols, lab, _ = _bind_brats(params, intensities, labels, None, ext, dev, pred_stream=True)
+    if any(v is None for v in vols):
+        raise ValueError("the MLP reads all four modalities: bind gIntensity0..3")
+    if E.tileWorld > 1:
+        raise ValueError("render_brats_inr renders whole frames")
+    w, h = int(P.imageSize[0]), int(P.imageSize[1])
+    lib, s = _lib.lib(), _stream_ptr(None)
+    vp = (C.c_void_p * 4)(*[C.c_void_p(t.data_ptr()) for t in vols])
+    counts = torch.empty(h * w, dtype=torch.int32, device=dev)
+    _lib.check(lib.mrirt_brats_sample_counts(C.byref(P), C.byref(E), _ptr(counts), s), "mrirt_brats_sample_counts")
+    ends = torch.cumsum(counts.to(torch.int64), 0)
+    offsets = (ends - counts).contiguous()
+    total = int(ends[-1])
+    coords = torch.empty((max(total, 1), 3), dtype=torch.float32, device=dev)
+    feats = torch.empty((max(total, 1), 4), dtype=torch.float32, device=dev)
+    classes = torch.zeros(max(total, 1), dtype=torch.int16, device=dev)
+    mu = (C.c_float * 4)(*[float(np.float32(v)) for v in zmu])
+    sg = (C.c_float * 4)(*[float(np.float32(v)) for v in zsigma])
+    _lib.check(lib.mrirt_brats_emit_samples(C.byref(P), C.byref(E), vp, mu, sg, _ptr(offsets), _ptr(coords), _ptr(feats), s),
+               "mrirt_brats_emit_samples")
+    if total:
+        _lib.check(lib.mrirt_inr_forward(C.byref(net.desc), _ptr(coords), _ptr(feats), total, None, _ptr(classes), s),
+                   "mrirt_inr_forward")
+    o, pitch = _alloc_out(w, h, E, dev, out)
+    _lib.check(lib.mrirt_render_brats_stream(C.byref(P), C.byref(E), vp, _ptr(lab), _ptr(classes), _ptr(offsets),
+                                             _ptr(o), pitch, None, s), "mrirt_render_brats_stream")
+    if return_aux:
+        return o, dict(queries=total, classes=classes, offsets=offsets, coords=coords, feats=feats, counts=counts)
+    return o
+
+
 def labels_for_viewer(pred_hwd: torch.Tensor) -> torch.Tensor:
     """pred (H,W,D) -> the viewer's x-fastest uint32 label buffer (brats_viewer.py:297-299)."""
     return pred_hwd.permute(2, 1, 0).reshape(-1).to(torch.int32).contiguous()

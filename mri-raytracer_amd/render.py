@@ -144,18 +144,9 @@ def _alloc_out(params_w: int, params_h: int, ext: _lib.RenderExt, dev, out):
     return out, out.stride(0) // 4
 
 
-def render_brats(params: Mapping[str, Any], intensities: Sequence[Optional[Union[ArrayLike, Grid]]],
-                 labels: Optional[Union[ArrayLike, Grid]] = None, preds: Optional[Union[ArrayLike, Grid]] = None,
-                 out: Optional[torch.Tensor] = None, ext: Optional[Mapping[str, Any]] = None,
-                 stats: bool = False, stream=None):
-    """K1 — drop-in for ``kernel.dispatch`` of ``brats_main`` (inr/viewer/brats_viewer.py:431-442).
-
-    ``params`` is the reference's ``gParams`` dict; ``intensities`` are ``gIntensity0..3``,
-    ``labels``/``preds`` are ``gLabels``/``gPreds``.  Returns the fp32 (H,W,4) frame (or the
-    compact tile buffer when ``ext`` shards tiles).  With ``stats=True`` also returns
-    ``{"live_samples", "shaded_samples"}`` counted on the device.
-    """
-    dev = _require_gpu()
+def _bind_brats(params, intensities, labels, preds, ext, dev, pred_stream: bool = False):
+    """gParams dict + bound grids -> (MrirtBratsParams, MrirtRenderExt, device tensors), with the
+    layout / size checks every K1 entry point shares."""
     P = brats_params(params)
     e = dict(ext or {})
     vgrids = [g for g in intensities if isinstance(g, Grid)]
@@ -187,8 +178,24 @@ def render_brats(params: Mapping[str, Any], intensities: Sequence[Optional[Union
     prd = _as_device_tensor(preds, torch.int32, dev, "gPreds")
     if P.showSeg != 0 and (lab is None or lab.numel() < need[lab_lay]):
         raise ValueError("showSeg is set but gLabels is missing or too small")
-    if P.showPred != 0 and (prd is None or prd.numel() < need[lab_lay]):
+    if P.showPred != 0 and not pred_stream and (prd is None or prd.numel() < need[lab_lay]):
         raise ValueError("showPred is set but gPreds is missing or too small")
+    return P, E, vols, lab, prd
+
+
+def render_brats(params: Mapping[str, Any], intensities: Sequence[Optional[Union[ArrayLike, Grid]]],
+                 labels: Optional[Union[ArrayLike, Grid]] = None, preds: Optional[Union[ArrayLike, Grid]] = None,
+                 out: Optional[torch.Tensor] = None, ext: Optional[Mapping[str, Any]] = None,
+                 stats: bool = False, stream=None):
+    """K1 — drop-in for ``kernel.dispatch`` of ``brats_main`` (inr/viewer/brats_viewer.py:431-442).
+
+    ``params`` is the reference's ``gParams`` dict; ``intensities`` are ``gIntensity0..3``,
+    ``labels``/``preds`` are ``gLabels``/``gPreds``.  Returns the fp32 (H,W,4) frame (or the
+    compact tile buffer when ``ext`` shards tiles).  With ``stats=True`` also returns
+    ``{"live_samples", "shaded_samples"}`` counted on the device.
+    """
+    dev = _require_gpu()
+    P, E, vols, lab, prd = _bind_brats(params, intensities, labels, preds, ext, dev)
     o, pitch = _alloc_out(int(P.imageSize[0]), int(P.imageSize[1]), E, dev, out)
     vp = (C.c_void_p * 4)(*[C.c_void_p(t.data_ptr()) if t is not None else None for t in vols])
     st = torch.zeros(2, dtype=torch.int64, device=dev) if stats else None

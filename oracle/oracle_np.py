@@ -354,7 +354,10 @@ def brats_main(params: Dict[str, Any], vols: Sequence[Optional[np.ndarray]],
 
         for show, buf, mul in ((showSeg, labels, None), (showPred, preds, F(1.5))):
             if show != 0:
-                l = _sample_label(buf, qx, qy, qz, X, Y, Z).astype(np.int64)
+                if callable(buf):      # per-sample label source (INR query / class stream), extension
+                    l = np.asarray(buf(idx, nsteps[idx], qx, qy, qz)).astype(np.int64)
+                else:
+                    l = _sample_label(buf, qx, qy, qz, X, Y, Z).astype(np.int64)
                 okl = (l > 0) & (l < 8)
                 col = lut[np.where(okl, l, 0)]
                 arg = -col[:, 3] * step
@@ -790,6 +793,44 @@ def siren_apply(params, x, w0: float = 30.0):
         h = np.sin(F(w0) * z + _f(p["b"])) if i == 0 else np.sin(z + _f(p["b"]))
     p = params[f"l{n - 1}"]
     return h @ _f(p["w"]) + _f(p["b"])
+
+
+def inr_sample_inputs(vols, dims, zmu, zsigma, qx, qy, qz):
+    """BUILD-DEFINED (BASELINE config 5): MLP inputs of a march sample at index-space position q.
+    coords = 2*clamp(q,0,dim-1)/(dim-1) - 1 (fp64, rounded once — at a lattice point this is exactly
+    predict_volume's coordinate, inr/inr/model.py:124-128); intensities = the four trilinear
+    samples (sampleLinear), z-scored with the viewer's per-modality constants,
+    (v - mu) / sigma (inr/viewer/brats_viewer.py:281-287)."""
+    X, Y, Z = dims
+    c = []
+    for q, d in ((qx, X), (qy, Y), (qz, Z)):
+        qc = np.minimum(np.maximum(q, _ZERO), F(d) - _ONE).astype(np.float64)
+        c.append(((qc / np.float64(d - 1)) * 2.0 - 1.0).astype(np.float32))
+    feats = []
+    for m in range(4):
+        v, _ = _sample_linear(vols[m], qx, qy, qz, X, Y, Z)
+        feats.append((v - F(zmu[m])) / F(zsigma[m]))
+    return np.stack(c, axis=-1), np.stack(feats, axis=-1)
+
+
+def brats_main_inr(params, vols, mlp_params, fourier_freqs, zmu, zsigma, labels=None, ext=None, *,
+                   class_stream=None, ray_offsets=None, return_aux=False):
+    """K1 with the prediction overlay's label taken from an MLP query at every sample instead of
+    sampleLabel(gPreds).  ``showPred`` must be set.  With
+    ``class_stream``/``ray_offsets`` the labels are read from a per-ray stream (class of sample k of
+    pixel p at class_stream[ray_offsets[p] + k]) — used to check the compositing pass against the
+    GPU's own bf16 classes."""
+    dims = tuple(int(v) for v in params["dims"])
+    Wd = int(params["imageSize"][0])
+
+    def source(idx, k, qx, qy, qz):
+        if class_stream is not None:
+            return class_stream[ray_offsets[idx] + k]
+        c, f = inr_sample_inputs(vols, dims, zmu, zsigma, qx, qy, qz)
+        return np.argmax(apply_mlp(mlp_params, build_input(c, f, fourier_freqs)), axis=-1)
+
+    del Wd
+    return brats_main(params, vols, labels, source, ext, return_aux=return_aux)
 
 
 def model_load(npz_path, config_override=None):
