@@ -123,15 +123,17 @@ __device__ __forceinline__ float input_feature(const InrArgs& a, uint32_t f, int
         if (g < 6 * a.K) {
             const uint32_t axis = g / (2 * a.K), rem = g % (2 * a.K);
             const bool isSin = rem < a.K;
-            const float ang = (c[axis] * (float)((isSin ? rem : rem - a.K) + 1)) * 3.14159274101257324f;
-            return isSin ? sinf(ang) : cosf(ang);
+            // sin(pi k c) / cos(pi k c): v_sin_f32 / v_cos_f32 take revolutions, k c / 2 (|.| <= 8 at K = 16);
+            // their ~1e-6 absolute error is far below the split-bf16 resolution of the layer-0 operands
+            const float rev = (c[axis] * (float)((isSin ? rem : rem - a.K) + 1)) * 0.5f;
+            return isSin ? __builtin_amdgcn_sinf(rev) : __builtin_amdgcn_cosf(rev);
         }
         g -= 6 * a.K;
     }
     return a.volume ? a.feats[(size_t)g * ((size_t)a.H * a.W * a.D) + p] : a.feats[p * (int64_t)a.M + g];
 }
 
-template <int HID, int KT0>
+template <int HID, int KT0, bool SIREN>
 __global__ __launch_bounds__(512) void inr_forward_kernel(const InrArgs a) {
     constexpr int KT = HID / 32;                         // k tiles of a hidden-wide input == out tiles of a hidden-wide output
     constexpr int OTC = KT < 4 ? KT : 4;                 // out tiles per chunk (one barrier per chunk)
@@ -144,7 +146,7 @@ __global__ __launch_bounds__(512) void inr_forward_kernel(const InrArgs a) {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, r = lane & 31u, h = lane >> 5;
     const int64_t base = ((int64_t)blockIdx.x * kInrWaves + wave) * 32;
     const uint4* __restrict__ wp = a.wpack;
-    const bool siren = a.kind == MRIRT_INR_SIREN || a.kind == 3u;
+    constexpr bool siren = SIREN;                        // sin activations (kinds 1, 3) vs ReLU (kinds 0, 2)
 
     // ---- chunk streaming: LDS-DMA, one 1-KiB fragment per wave-instruction (lane-linear image) -----------
     auto stage_issue = [&](uint32_t fragStart, int nfrag, int dstBuf) {
@@ -311,8 +313,14 @@ template <int HID>
 static int launch_inr_kt0(const InrArgs& a, hipStream_t s) {
     const int64_t groups = (a.n + kInrWaves * 32 - 1) / (kInrWaves * 32);
     const dim3 grid((uint32_t)groups), block(kInrWaves * 64);
-    if (a.L.kt0 == 1) hipLaunchKernelGGL((inr_forward_kernel<HID, 1>), grid, block, 0, s, a);
-    else              hipLaunchKernelGGL((inr_forward_kernel<HID, 4>), grid, block, 0, s, a);
+    const bool siren = a.kind == MRIRT_INR_SIREN || a.kind == 3u;
+    if (a.L.kt0 == 1) {
+        if (siren) hipLaunchKernelGGL((inr_forward_kernel<HID, 1, true>), grid, block, 0, s, a);
+        else       hipLaunchKernelGGL((inr_forward_kernel<HID, 1, false>), grid, block, 0, s, a);
+    } else {
+        if (siren) hipLaunchKernelGGL((inr_forward_kernel<HID, 4, true>), grid, block, 0, s, a);
+        else       hipLaunchKernelGGL((inr_forward_kernel<HID, 4, false>), grid, block, 0, s, a);
+    }
     MRIRT_HIP(hipGetLastError());
     return MRIRT_OK;
 }

@@ -53,3 +53,23 @@ rows.append(("C2-1ch 256^3 512^2 256 quad strict", "", ms, sts["live_samples"], 
 print(f"{'config':48s} {'GPU ms':>8s} {'live Ms':>9s} {'Gsamp/s':>8s} {'max|err|':>9s}  cpu")
 for name, cpu, ms, live, err in rows:
     print(f"{name:48s} {ms:8.3f} {live/1e6:9.2f} {live/ms/1e6:8.2f} {err:9.2e}  {cpu}")
+
+# ---- C5: per-sample INR query, 512^2 x 256 steps on the 256^3 4-modality scene, Fourier/ReLU 103 -> 4x256 -> 4
+from mrirt import inr
+import math
+rng = np.random.default_rng(0)
+K = 16
+sizes = [3 + 6 * K + 4] + [256] * 4 + [4]
+mlp = [{"W": (rng.uniform(-1, 1, (sizes[i], sizes[i+1])) * math.sqrt(6 / (sizes[i] + sizes[i+1]))).astype(np.float32),
+        "b": np.zeros(sizes[i+1], np.float32)} for i in range(5)]
+net = inr.pack_mlp(mlp, inr.KIND_FOURIER_RELU, K, 4)
+zmu = [float(v[v != 0].mean()) for v in vols]
+zsg = [float(v[v != 0].std() + 1e-6) for v in vols]
+p5 = synth.brats_scene(n, 512, 256, channels=4, show_seg=True, show_pred=True, intensity_alpha=0.4)
+gv = [mrirt.upload_grid(v, (n, n, n), "quad") for v in vols]
+gl = mrirt.upload_grid(lab, (n, n, n), "brick")
+img, aux = inr.render_brats_inr(p5, gv, net, zmu, zsg, labels=gl, return_aux=True)
+ms5 = timeit(lambda: inr.render_brats_inr(p5, gv, net, zmu, zsg, labels=gl), rounds=5)
+flop = 2 * sum(sizes[i] * sizes[i+1] for i in range(5))
+print(f"C5 256^3x4ch 512^2 256 steps, Fourier 103-4x256-4: {ms5:.2f} ms/frame, {aux['queries']/1e6:.1f} M MLP queries (every sample in [t0,t1)), "
+      f"{aux['queries']/ms5/1e3:.0f} Mquery/s end to end, {flop*aux['queries']/ms5/1e9:.0f} TFLOP/s end to end")
