@@ -13,10 +13,12 @@
 // per (out tile, k step): an A fragment is one 16-byte read per lane.
 //
 // Work split: a workgroup is 8 waves (2 per SIMD, so one wave's activations overlap the other's
-// MFMAs); each wave owns 32 points.  The weights of one out tile (<= 16 KiB) are a "chunk": chunks
-// are consecutive in the packed image, staged global -> registers -> LDS one chunk ahead (double
-// buffer, one barrier per chunk) and read by all 8 waves with conflict-free ds_read_b128.  Weight
-// traffic from L2 is thus 16 KiB per 256 points per chunk instead of per 64 points per wave.
+// MFMAs); each wave owns 32 points.  The weights of up to four out tiles (<= 64 KiB) are a "chunk":
+// chunks are consecutive in the packed image and are staged one chunk ahead by LDS-DMA
+// (global_load_lds, one 1-KiB fragment per wave-instruction into a lane-linear image; double buffer,
+// one barrier per chunk), then read by all 8 waves with conflict-free ds_read_b128.  Weight traffic
+// from L2 is thus one pass of the network per 256 points, and the biases sit in LDS too, so the
+// loop's only vector-memory traffic is the DMA.
 //
 // Precision: bf16 operands, fp32 accumulate.  The FIRST layer sees raw coordinates and Fourier
 // features (sin(pi k c), k <= 16) and, for the SIREN, a 30x frequency scale, so its inputs and weights
@@ -141,7 +143,15 @@ __global__ __launch_bounds__(512) void inr_forward_kernel(const InrArgs a) {
     constexpr int CH0 = OTC * F0, CHH = OTC * FH;        // fragments per chunk
     constexpr int CHMAX = CH0 > CHH ? CH0 : CHH;
     constexpr int PERW = (CHMAX + kInrWaves - 1) / kInrWaves;
-    __shared__ uint4 lds[2][CHMAX * 64];                 // 2 x <=64 KiB, the only LDS object (guide G17)
+    constexpr int kBiasQ = kMaxLayers * 256 / 4;         // every layer's padded biases, as float4
+    __shared__ uint4 ldsAll[2 * CHMAX * 64 + kBiasQ];    // 2 weight buffers (<= 64 KiB each) + biases: ONE LDS object (G17)
+    uint4 (*lds)[CHMAX * 64] = reinterpret_cast<uint4 (*)[CHMAX * 64]>(ldsAll);
+    const float4* ldsBias = reinterpret_cast<const float4*>(ldsAll + 2 * CHMAX * 64);
+    {   // biases: global -> LDS once, so the loop's only vector-memory traffic is the weight LDS-DMA
+        const uint32_t nq = (a.L.biasOff[a.L.numLayers - 1] + 32) / 4;
+        for (uint32_t i = threadIdx.x; i < nq; i += blockDim.x)
+            ldsAll[2 * CHMAX * 64 + i] = reinterpret_cast<const uint4*>(a.bias)[i];
+    }
 
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, r = lane & 31u, h = lane >> 5;
     const int64_t base = ((int64_t)blockIdx.x * kInrWaves + wave) * 32;
@@ -199,9 +209,9 @@ __global__ __launch_bounds__(512) void inr_forward_kernel(const InrArgs a) {
     bf16x8 Hn[KT][2];            // next layer's input, built out tile by out tile
 
     // bias of out tile o for this lane half: rows 8g + 4h .. +3 (g = 0..3) = four aligned float4
-    auto load_bias = [&](const float* __restrict__ bias, int o, float4 b4[4]) {
+    auto load_bias = [&](uint32_t layerOff, int o, float4 b4[4]) {       // from the LDS copy (ds_read_b128)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) b4[g] = *reinterpret_cast<const float4*>(bias + 32 * o + 8 * g + 4 * h);
+        for (int g = 0; g < 4; ++g) b4[g] = ldsBias[(layerOff + 32 * o + 8 * g + 4 * h) >> 2];
     };
     auto activate = [&](const f32x16& acc, const float4 b4[4], int o, bool first) {
 #pragma unroll
@@ -227,7 +237,7 @@ __global__ __launch_bounds__(512) void inr_forward_kernel(const InrArgs a) {
 
     // ---- layer 0: hi/lo split, three products per k step -------------------------------------------------
     {
-        const float* __restrict__ b0 = a.bias + a.L.biasOff[0];
+        const uint32_t b0 = a.L.biasOff[0];
 #pragma unroll
         for (int og = 0; og < KT / OTC; ++og) {
             const int nfragNext = (og + 1 < KT / OTC) ? CH0 : (a.L.numLayers > 2 ? CHH : FH);   // layer 0 / layer 1 / head
@@ -258,7 +268,7 @@ __global__ __launch_bounds__(512) void inr_forward_kernel(const InrArgs a) {
     for (uint32_t l = 1; l + 1 < a.L.numLayers; ++l) {
 #pragma unroll
         for (int t = 0; t < KT; ++t) { Hc[t][0] = Hn[t][0]; Hc[t][1] = Hn[t][1]; }
-        const float* __restrict__ bl = a.bias + a.L.biasOff[l];
+        const uint32_t bl = a.L.biasOff[l];
         const bool lastHidden = l + 2 == a.L.numLayers;
 #pragma unroll
         for (int og = 0; og < KT / OTC; ++og) {
