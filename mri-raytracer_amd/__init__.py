@@ -12,7 +12,7 @@ the task-mandated name ``mri-raytracer_amd``.  Layout:
   tiles.py    image-tile sharding + RCCL framebuffer gather (one process per GPU)
   synth.py    deterministic synthetic scenes for tests and bench
 """
-from . import _lib, camera, inr, params, render, shim, synth, tiles, volume  # noqa: F401
+from . import _lib, camera, inr, nifti, params, render, shim, synth, tiles, viewer, volume  # noqa: F401
 from .camera import OrbitalCamera  # noqa: F401
 from .shim import Device, KernelShim  # noqa: F401
 from .render import (Grid, detile, render_brats, render_sdf, render_volume_u8, tiles_for_rank,  # noqa: F401

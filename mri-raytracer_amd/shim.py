@@ -76,9 +76,10 @@ class Buffer:
         dims = tuple(int(d) for d in dims)
         if layout == "linear" or self.tensor.numel() < dims[0] * dims[1] * dims[2]:
             return _r.Grid(self.tensor, dims, "linear")
-        if dims not in self._bricked:
-            self._bricked[dims] = _r.upload_grid(self.tensor[:dims[0] * dims[1] * dims[2]], dims, "brick")
-        return self._bricked[dims]
+        key = (dims, layout)
+        if key not in self._bricked:
+            self._bricked[key] = _r.upload_grid(self.tensor[:dims[0] * dims[1] * dims[2]], dims, layout)
+        return self._bricked[key]
 
 
 class Texture:
@@ -157,10 +158,15 @@ class ComputeKernel:
         raw = [vars[f"gIntensity{m}"] for m in range(4)] + [vars["gLabels"], vars["gPreds"]]
         if not all(isinstance(b, Buffer) for b in raw):
             layout = "linear"
+        # "auto": float4 voxels in 2x2x2 bricks — value+gradient when shading, xy-quads otherwise;
+        # label grids in 4x4x2 bricks.  Derived copies are cached on the Buffer until it is rewritten.
+        vlay = ("vg" if int(e.get("shadeMode", 0)) else "quad") if layout == "auto" else layout
+        llay = "linear" if layout == "linear" else "brick"
         # dummy 1-element buffers stand in for disabled inputs (brats_viewer.py:247-248,437-438)
         en = [int(v) != 0 for v in p["volEnabled"]] + [int(p["showSeg"]) != 0, int(p["showPred"]) != 0]
-        bound = [self._buf(b, dims, layout) if on else None for b, on in zip(raw, en)]
-        e["layout"] = e["labelLayout"] = layout
+        lays = [vlay] * 4 + [llay] * 2
+        bound = [self._buf(b, dims, lay) if on else None for b, on, lay in zip(raw, en, lays)]
+        e["layout"], e["labelLayout"] = vlay, llay
         _r.render_brats(p, bound[:4], bound[4], bound[5], out=tex.tensor, ext=e)
 
     def _volume(self, tc, vars, ext):
@@ -182,11 +188,12 @@ class ComputeKernel:
 
 
 class Device:
-    """Stands where ``spy.Device(...)`` stands.  ``layout='brick'`` (default) lets K1 march the
-    bricked copy of each bound Buffer; ``math`` selects the strict or fast arithmetic flavour."""
+    """Stands where ``spy.Device(...)`` stands.  ``layout='auto'`` (default) lets K1 march a
+    float4-bricked copy of each bound Buffer (see ComputeKernel._brats; 'linear' binds the buffers
+    as uploaded, like the reference); ``math`` selects the strict or fast arithmetic flavour."""
 
     def __init__(self, enable_debug_layers: bool = False, compiler_options: Optional[dict] = None,
-                 layout: str = "brick", math: str = "strict"):
+                 layout: str = "auto", math: str = "strict"):
         self.torch_device = _r._require_gpu()
         self.default_ext = {"layout": layout, "math": math}
 
