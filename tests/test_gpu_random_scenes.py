@@ -1,0 +1,117 @@
+"""Randomised and edge-case parity of K1 (STRICT) against the C oracle: the bit-faithfulness claim
+has to hold for arbitrary cameras, grid shapes, clip planes, transfer functions and layouts, not only
+for the bench scene."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-6
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    import mrirt
+    from mrirt import synth
+    from oracle import oracle_c
+    assert torch.cuda.is_available()
+    return mrirt, synth, oracle_c
+
+
+def _render_both(env, p, vols, lab, prd, ext, layout):
+    mrirt, synth, oc = env
+    dims = tuple(int(v) for v in p["dims"])
+    okeys = ("cameraMode", "orthoHalfHeight", "shadeMode", "ka", "kd", "ks", "specPow2", "gradEps", "ertThreshold")
+    ref, aux = oc.brats_main(p, vols, lab, prd, {k: v for k, v in (ext or {}).items() if k in okeys}, return_aux=True)
+    lab_layout = "linear" if layout == "linear" else "brick"
+    g = [mrirt.upload_grid(v, dims, layout) for v in vols]
+    gl, gp = mrirt.upload_grid(lab, dims, lab_layout), mrirt.upload_grid(prd, dims, lab_layout)
+    img, st = mrirt.render_brats(p, g, gl, gp, ext=dict(ext or {}, math="strict"), stats=True)
+    return img.cpu().numpy(), st, ref, aux
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_scene(env, seed):
+    mrirt, synth, oc = env
+    rng = np.random.default_rng(1000 + seed)
+    dims = tuple(int(v) for v in rng.integers(2, 40, 3))
+    vols = [synth.synth_volume(0, seed * 7 + m, phase=float(rng.uniform(0, 3)), dims=dims) for m in range(4)]
+    lab = (synth.synth_labels(0, dims=dims) + rng.integers(0, 2, dims[0] * dims[1] * dims[2]).astype(np.uint32) * 9) % 11
+    lab = lab.astype(np.uint32)
+    prd = np.roll(lab, 5).copy()
+    cam = synth.bench_camera(radius=float(rng.uniform(0.3, 4.0)), phi_deg=float(rng.uniform(3, 177)),
+                             theta_deg=float(rng.uniform(0, 360)))
+    shade = bool(rng.integers(0, 2))
+    p = synth.brats_scene(0, 0, int(rng.integers(6, 120)), dims=dims,
+                          image_hw=(int(rng.integers(1, 60)), int(rng.integers(1, 60))),
+                          channels=int(rng.integers(0, 5)), show_seg=bool(rng.integers(0, 2)),
+                          show_pred=bool(rng.integers(0, 2)), intensity_alpha=float(rng.choice([0.4, 3.0, 16.0, 80.0])),
+                          camera=cam, fov_deg=float(rng.uniform(15, 100)))
+    p["nearT"], p["farT"] = float(rng.choice([0.0, 0.7, 2.0])), float(rng.choice([0.0, 2.5, 0.5]))
+    p["gamma"] = float(rng.choice([1.0, 1.0, 0.6, 2.2]))
+    p["ww"], p["wl"] = float(rng.choice([1.0, 0.5, 2.0])), float(rng.choice([0.5, 0.3]))
+    p["bgColor"] = rng.random(3).astype(np.float32)
+    p["volWeight"] = tuple(float(v) for v in rng.uniform(0.1, 3.0, 4))
+    p["voxelSize"] = (p["voxelSize"] * rng.uniform(0.5, 2.0, 3)).astype(np.float32)     # anisotropic voxels
+    ext = dict(synth.SHADE_EXT, cameraMode=int(rng.integers(0, 2)), orthoHalfHeight=float(rng.uniform(0.5, 1.5))) if shade else \
+        dict(cameraMode=int(rng.integers(0, 2)), orthoHalfHeight=1.0)
+    layouts = ["linear", "brick", "vg"] + ([] if shade else ["quad"])
+    layout = layouts[int(rng.integers(0, len(layouts)))]
+    got, st, ref, aux = _render_both(env, p, vols, lab, prd, ext, layout)
+    assert np.abs(got - ref).max() <= TOL, (seed, layout, dims, np.abs(got - ref).max())
+    assert st["live_samples"] == aux["live_samples"] and st["shaded_samples"] == aux["shaded_samples"]
+
+
+def test_camera_inside_volume_and_axis_aligned_rays(env):
+    mrirt, synth, oc = env
+    dims = (16, 16, 16)
+    vols = [synth.synth_volume(16, 3)]
+    lab = synth.synth_labels(16)
+    from mrirt.camera import OrbitalCamera
+    # eye at the box centre, looking down an axis: tmin < 0, two direction components are exactly 0
+    # at the centre pixel of an odd-sized image (the 1e-6 nudge of brats_rt.slang:96-98)
+    cam = OrbitalCamera(initial_radius=0.0)
+    p = synth.brats_scene(16, 0, 40, image_hw=(33, 33), channels=1, show_seg=True, intensity_alpha=3.0, camera=cam)
+    p["eye"], p["U"], p["V"], p["W"] = (np.float32([0, 0, 0]), np.float32([1, 0, 0]), np.float32([0, 1, 0]),
+                                         np.float32([0, 0, -1]))
+    got, st, ref, aux = _render_both(env, p, vols * 4, lab, lab, None, "quad")
+    assert np.abs(got - ref).max() <= TOL and st["live_samples"] == aux["live_samples"] > 0
+    # orthographic, exactly axis-aligned: every ray has two zero direction components
+    p2 = synth.brats_scene(16, 0, 40, image_hw=(24, 20), channels=1, intensity_alpha=3.0)
+    p2["eye"], p2["U"], p2["V"], p2["W"] = (np.float32([0, 0, 3]), np.float32([1, 0, 0]), np.float32([0, 1, 0]),
+                                            np.float32([0, 0, -1]))
+    got, st, ref, aux = _render_both(env, p2, vols * 4, lab, lab, dict(cameraMode=1, orthoHalfHeight=1.0), "brick")
+    assert np.abs(got - ref).max() <= TOL and st["live_samples"] == aux["live_samples"] > 0
+
+
+def test_division_fallback_when_reciprocal_is_not_exact(env):
+    """A voxelSize / ww / weight-sum whose significand is all ones is the one case Markstein's
+    division excludes: the kernel must fall back to a true divide and stay bit-faithful."""
+    mrirt, synth, oc = env
+    dims = (12, 10, 8)
+    vols = [synth.synth_volume(0, 5 + m, dims=dims) for m in range(4)]
+    lab = synth.synth_labels(0, dims=dims)
+    ones = np.frombuffer(np.uint32(0x3DFFFFFF).tobytes(), np.float32)[0]          # 0.12499999, significand all ones
+    p = synth.brats_scene(0, 0, 48, dims=dims, image_hw=(30, 36), channels=2, intensity_alpha=6.0)
+    p["voxelSize"] = np.float32([ones, 0.15, ones])
+    p["volMin"] = (-0.5 * p["voxelSize"] * np.float32(dims)).astype(np.float32)
+    p["ww"] = float(np.frombuffer(np.uint32(0x3F7FFFFF).tobytes(), np.float32)[0])      # 0.99999994
+    p["volWeight"] = (float(np.frombuffer(np.uint32(0x3EFFFFFF).tobytes(), np.float32)[0]),) * 4   # sums to 0.99999994
+    for layout in ("linear", "quad"):
+        got, st, ref, aux = _render_both(env, p, vols, lab, lab, None, layout)
+        assert np.abs(got - ref).max() <= TOL and st["live_samples"] == aux["live_samples"]
+
+
+def test_no_modality_enabled_and_lut_edge_labels(env):
+    mrirt, synth, oc = env
+    dims = (10, 9, 8)
+    vols = [synth.synth_volume(0, 1, dims=dims)] * 4
+    lab = (np.arange(dims[0] * dims[1] * dims[2]) % 10).astype(np.uint32)      # labels 0..9: 8 and 9 are ignored (:145)
+    p = synth.brats_scene(0, 0, 40, dims=dims, image_hw=(20, 28), channels=0, show_seg=True, show_pred=True)
+    lut = np.array(p["lutColorAlpha"], np.float32)
+    lut[5], lut[6], lut[7] = [0.2, 0.9, 0.4, 2.5], [0.7, 0.7, 0.1, 0.0], [0.3, 0.1, 0.8, 40.0]
+    p["lutColorAlpha"] = [tuple(map(float, r)) for r in lut]
+    got, st, ref, aux = _render_both(env, p, vols, lab, np.roll(lab, 3), None, "brick")
+    assert np.abs(got - ref).max() <= TOL and st["live_samples"] == aux["live_samples"]
+    assert ref[..., :3].max() > 0.1
