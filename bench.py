@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--tile", type=int, default=64)
     ap.add_argument("--cpu-rows", type=int, default=-1, help="rows of the frame the CPU baseline renders; 0 = skip, -1 = auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="N=1 only: still create the RCCL group (world size 1), render compact tiles and run the "
+                         "asynchronous all-gather + de-tiling path — a single-GPU rehearsal of the N>1 code")
     return ap.parse_args()
 
 
@@ -118,8 +121,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the ray-marcher has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    grouped = world > 1 or a.force_exchange
+    if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     n = a.volume
@@ -133,7 +138,7 @@ def main():
     grid = mrirt.upload_grid(vol, (n, n, n), a.layout)            # resident in HBM (bricked on device)
     torch.cuda.synchronize()
 
-    if world > 1:
+    if grouped:
         my_ext = tiles.shard_ext(ext, rank, world, a.tile)
         # double-buffered asynchronous exchange: frame k's all-gather overlaps frame k+1's march
         ex = tiles.FrameExchange(image, image, a.tile, torch.float32, dev, depth=2, dst=0)
@@ -170,7 +175,7 @@ def main():
 
     run_frames(a.warmup)
     torch.cuda.synchronize()
-    if world > 1:
+    if grouped:
         dist.barrier()
     torch.cuda.synchronize()
 
@@ -180,7 +185,7 @@ def main():
     # the wall clock brackets the whole K steps incl. every exchange and de-tiling (value)
     run_frames(a.steps, ev)
     torch.cuda.synchronize()
-    if world > 1:
+    if grouped:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -224,7 +229,7 @@ def main():
         if not a.no_cpu_baseline and a.cpu_rows != 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(params, vol, ext, min(a.cpu_rows, image), image)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if grouped:
         dist.destroy_process_group()
 
 

@@ -98,7 +98,7 @@ typedef struct MrirtRenderExt {
     uint32_t outFormat;         /* MrirtOutFormat                                              */
     uint32_t layout;            /* MrirtLayout of ALL bound fp32 intensity grids               */
     uint32_t labelLayout;       /* MrirtLayout (LINEAR or BRICK) of the labels / preds grids   */
-    /* Image-tile sharding (one process per GPU).  tileWorld <= 1: whole image into
+    /* Image-tile sharding (one process per GPU).  tileSize == 0: whole image into
      * out[y*pitch + x].  Otherwise this call renders the tiles t with t % tileWorld ==
      * tileRank (t = ty*tilesX + tx, tiles of tileSize^2 pixels) into a COMPACT buffer
      * out[local_tile][tileSize][tileSize][4]; pitch is ignored.                            */

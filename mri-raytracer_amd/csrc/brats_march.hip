@@ -588,7 +588,7 @@ extern "C" int mrirt_render_brats_stream(const MrirtBratsParams* p, const MrirtR
                                          const int16_t* classes, const int64_t* offsets,
                                          void* out_rgba, int64_t pitch_px, uint64_t* stats_dev, void* stream) {
     if (!out_rgba || !classes || !offsets) return MRIRT_ERR_NULL;
-    if (ext && ext->tileWorld > 1) return MRIRT_ERR_ARG;         // whole-frame only
+    if (ext && ext->tileSize != 0) return MRIRT_ERR_ARG;         // whole-frame only
     K1Args a;
     Prepared cfg;
     int rc = prepare(p, ext, vol, labels, nullptr, true, pitch_px, a, cfg);
@@ -603,7 +603,7 @@ extern "C" int mrirt_render_brats_stream(const MrirtBratsParams* p, const MrirtR
 
 extern "C" int mrirt_brats_sample_counts(const MrirtBratsParams* p, const MrirtRenderExt* ext, uint32_t* counts, void* stream) {
     if (!counts) return MRIRT_ERR_NULL;
-    if (ext && ext->tileWorld > 1) return MRIRT_ERR_ARG;
+    if (ext && ext->tileSize != 0) return MRIRT_ERR_ARG;
     K1Args a;
     Prepared cfg;
     int rc = prepare(p, ext, nullptr, nullptr, nullptr, false, p ? p->imageSize[0] : 0, a, cfg);
@@ -632,7 +632,7 @@ extern "C" int mrirt_brats_emit_samples(const MrirtBratsParams* p, const MrirtRe
                                         float* coords, float* feats, void* stream) {
     if (!vol || !zmu || !zsigma || !offsets || !coords || !feats) return MRIRT_ERR_NULL;
     for (int m = 0; m < 4; ++m) if (!vol[m]) return MRIRT_ERR_NULL;          // the MLP reads all four modalities
-    if (ext && ext->tileWorld > 1) return MRIRT_ERR_ARG;
+    if (ext && ext->tileSize != 0) return MRIRT_ERR_ARG;
     K1Args a;
     Prepared cfg;
     int rc = prepare(p, ext, vol, nullptr, nullptr, false, p ? p->imageSize[0] : 0, a, cfg);

@@ -172,7 +172,7 @@ struct PixelMap {
     uint32_t width, height;
     uint32_t blocksX, numBlocks;       // 16x16-pixel workgroups over the part of the image this call renders
     uint32_t chunk;                    // ceil(numBlocks / 8): logical ids one XCD owns
-    uint32_t tileSize, tileRank, tileWorld, tilesX;   // tileWorld <= 1: whole frame
+    uint32_t tileSize, tileRank, tileWorld, tilesX;   // tileSize == 0: whole frame
     uint32_t laneOrder;                // 0 row-major 8x8 packet, 1 Morton (2x2 pixel quads per 4 lanes)
     uint32_t blockPx;                  // 16: 256-thread workgroups (2x2 packets); 8: one packet per workgroup
     int64_t  pitch;                    // pixels per output row (whole-frame mode)
@@ -196,7 +196,7 @@ __device__ __forceinline__ int map_pixel(const PixelMap& m, uint32_t& px, uint32
         ly = ((lane >> 1) & 1u) | ((lane >> 2) & 2u) | ((lane >> 3) & 4u);
     }
     lx += (wave & 1u) << 3; ly += (wave >> 1) << 3;
-    if (m.tileWorld <= 1) {
+    if (m.tileSize == 0) {
         uint32_t bx = logical % m.blocksX, by = logical / m.blocksX;
         px = bx * m.blockPx + lx; py = by * m.blockPx + ly;
         outIndex = (int64_t)py * m.pitch + px;

@@ -62,13 +62,13 @@ inline int fill_pixel_map(PixelMap& m, uint32_t width, uint32_t height, int64_t 
     m.tileWorld = ext ? ext->tileWorld : 0u;
     m.laneOrder = laneOrder;
     m.blockPx = blockPx;
-    if (m.tileWorld <= 1) {
+    if (m.tileSize == 0) {
         if (pitch < (int64_t)width) return MRIRT_ERR_ARG;
         m.tilesX = 0;
         m.blocksX = (width + blockPx - 1) / blockPx;
         m.numBlocks = m.blocksX * ((height + blockPx - 1) / blockPx);
     } else {
-        if (m.tileSize == 0 || m.tileSize % kBlockPx != 0 || m.tileRank >= m.tileWorld) return MRIRT_ERR_ARG;
+        if (m.tileSize % kBlockPx != 0 || m.tileWorld == 0 || m.tileRank >= m.tileWorld) return MRIRT_ERR_ARG;
         m.tilesX = (width + m.tileSize - 1) / m.tileSize;
         int64_t local = mrirt_tiles_for_rank(width, height, m.tileSize, m.tileRank, m.tileWorld);
         uint32_t bpr = m.tileSize / blockPx;

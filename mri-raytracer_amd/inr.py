@@ -210,7 +210,7 @@ def render_brats_inr(params, intensities, net: PackedMLP, zmu, zsigma, labels=No
     P, E, vols, lab, _ = _bind_brats(params, intensities, labels, None, ext, dev, pred_stream=True)
     if any(v is None for v in vols):
         raise ValueError("the MLP reads all four modalities: bind gIntensity0..3")
-    if E.tileWorld > 1:
+    if E.tileSize > 0:
         raise ValueError("render_brats_inr renders whole frames")
     w, h = int(P.imageSize[0]), int(P.imageSize[1])
     lib, s = _lib.lib(), _stream_ptr(None)

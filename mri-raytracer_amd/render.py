@@ -126,7 +126,7 @@ def tiles_for_rank(width: int, height: int, tile: int, rank: int, world: int) ->
 
 def _alloc_out(params_w: int, params_h: int, ext: _lib.RenderExt, dev, out):
     dt = torch.float16 if ext.outFormat == _lib.OUT_RGBA16F else torch.float32
-    if ext.tileWorld > 1:
+    if ext.tileSize > 0:
         n = tiles_for_rank(params_w, params_h, ext.tileSize, ext.tileRank, ext.tileWorld)
         shape = (n, ext.tileSize, ext.tileSize, 4)
     else:
@@ -135,7 +135,7 @@ def _alloc_out(params_w: int, params_h: int, ext: _lib.RenderExt, dev, out):
         return torch.empty(shape, dtype=dt, device=dev), params_w
     if out.dtype != dt or not out.is_cuda or out.stride(-1) != 1:
         raise TypeError(f"out: expected a device {dt} tensor with unit channel stride")
-    if ext.tileWorld > 1:
+    if ext.tileSize > 0:
         if tuple(out.shape) != shape or not out.is_contiguous():
             raise ValueError(f"out: expected contiguous {shape}")
         return out, params_w

@@ -110,7 +110,7 @@ class FrameExchange:
         return self._send[i][:self.n_local]
 
     def submit(self, i: int) -> None:
-        if self.world == 1:
+        if not dist.is_initialized():                 # single process, no group: nothing to exchange
             self._recv[i].copy_(self._send[i])
             return
         self._work[i] = dist.all_gather_into_tensor(self._recv[i], self._send[i], group=self.group, async_op=True)

@@ -224,7 +224,7 @@ def test_tiles_compact_and_detile(env, scene48):
     p = synth.brats_scene(0, 0, 64, dims=dims, image_hw=(100, 150), channels=1, intensity_alpha=16.0)
     g = [mrirt.upload_grid(vols[0], dims, "brick")]
     full = mrirt.render_brats(p, g).cpu().numpy()
-    for world in (2, 3, 8):
+    for world in (1, 2, 3, 8):
         parts = []
         max_local = tiles.local_tile_count(150, 100, 32, 0, world)
         for r in range(world):
