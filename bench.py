@@ -100,9 +100,14 @@ def cpu_baseline(params, vol, ext, rows, n_image):
         if r1 - r0 < n_image:
             break
     cores = int(os.environ.get("OMP_NUM_THREADS", 0)) or (os.cpu_count() or 1)
+    try:
+        with open("/proc/cpuinfo") as fh:
+            cpu_model = next((ln.split(":", 1)[1].strip() for ln in fh if ln.startswith("model name")), "unknown CPU")
+    except OSError:
+        cpu_model = "unknown CPU"
     return {"value": round(live / dt / 1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
             "sample": f"rows {r0}..{r1 - 1} of the same {n_image}x{n_image} frame x {reps} pass(es) "
-                      f"({live} live samples in {dt:.1f} s; C/OpenMP oracle oracle/oracle_c.c, all host threads)"}
+                      f"({live} live samples in {dt:.1f} s; C/OpenMP oracle oracle/oracle_c.c, {cores} threads on {cpu_model})"}
 
 
 def main():
@@ -216,6 +221,7 @@ def main():
                        "tiles": f"{a.tile}x{a.tile} round-robin over {world} rank(s)",
                        "live_samples_per_frame": live, "shaded_samples_per_frame": shaded,
                        "nominal_samples_per_frame": image * image * a.march_steps,
+                       "effective_Msamples_s_nominal": round(image * image * a.march_steps * a.steps / elapsed / 1e6, 1),
                        "kernel_variant": a.variant},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
@@ -224,6 +230,7 @@ def main():
                              f"{'shade' if not a.no_shade else 'plain'}") if world == 1 and a.variant == 0 and a.alpha == 16.0 else None,
                          "kernel": "brats_march_pipe_kernel" if not a.variant & 4 else "brats_march_kernel", "kernel_ms": round(kernel_ms, 4),
                          "algorithmic_bytes_per_launch": alg_bytes,
+                         "compulsory_bytes_per_launch": grid.nbytes + px * BYTES_PER_PIXEL,   # volume once + framebuffer
                          "bytes_per_sample": BYTES_PER_SAMPLE + (0 if a.no_shade else BYTES_PER_SHADED)},
         }
         if not a.no_cpu_baseline and a.cpu_rows != 0 and world == 1:

@@ -14,6 +14,7 @@ the task-mandated name ``mri-raytracer_amd``.  Layout:
 """
 from . import _lib, camera, inr, nifti, params, render, shim, synth, tiles, viewer, volume  # noqa: F401
 from .camera import OrbitalCamera  # noqa: F401
+from .inr import apply_mlp, build_input, inr_forward, model_load, predict_volume, render_brats_inr  # noqa: F401
 from .shim import Device, KernelShim  # noqa: F401
 from .render import (Grid, detile, render_brats, render_sdf, render_volume_u8, tiles_for_rank,  # noqa: F401
                      unbrick_grid, upload_grid)
