@@ -198,14 +198,16 @@ __device__ __forceinline__ void fetch_labels(const K1Args& a, const Cell& s, Lab
     else l.pred = sample_label(a.preds, a.lab, s.q, a.hiLab);                       // :155
 }
 
-template <bool STRICT, bool SHADE>
+// GAMMA1: gamma == 1 (the viewer's constant, brats_viewer.py:422), where pow(val, 1) == val exactly;
+// compiling the fp64 pow out of the hot kernels frees the registers its temporaries would claim.
+template <bool STRICT, bool SHADE, bool GAMMA1 = false>
 __device__ __forceinline__ void composite(const K1Args& a, const float rd[3], const Labels& lb, float v, const float g[3],
                                           RayState& r) {
     using Mm = M<STRICT>;
     // wSum (brats_rt.slang:123-130) is the same for every sample: summed on the host
     if (a.wsum.d > 0.0f) v = Mm::divu(v, a.wsum);
     float val = satf(Mm::divu(v - a.tfLo, a.wwDiv));                 // :132
-    val = Mm::pow(val, a.gamma);                                     // :133
+    if constexpr (!GAMMA1) val = Mm::pow(val, a.gamma);              // :133
     ++r.nLive;
     if (val > 0.0f) {
         const float alpha = 1.0f - Mm::exp(-(val * a.intensityAlpha) * a.stepSize);
@@ -340,7 +342,7 @@ struct Stage {
         for (int c = 0; c < NCH; ++c) taps[c].issue(a.vol[a.chan[c]], a.grid, s);
         fetch_labels(a, s, lb);
     }
-    template <bool STRICT>
+    template <bool STRICT, bool GAMMA1>
     __device__ __forceinline__ void consume(const K1Args& a, const float rd[3], RayState& r) const {
         using Mm = M<STRICT>;
         float v = 0.0f, g[3] = { 0.0f, 0.0f, 0.0f };
@@ -355,11 +357,11 @@ struct Stage {
                 for (int k = 0; k < 3; ++k) g[k] = Mm::mad(gm[k], w, g[k]);
             }
         }
-        composite<STRICT, SHADE>(a, rd, lb, v, g, r);
+        composite<STRICT, SHADE, GAMMA1>(a, rd, lb, v, g, r);
     }
 };
 
-template <bool STRICT, int LAYOUT, bool SHADE, int NCH>
+template <bool STRICT, int LAYOUT, bool SHADE, int NCH, bool GAMMA1>
 __global__ __launch_bounds__(256, 3) void brats_march_pipe_kernel(const K1Args a) {
     uint32_t px, py;
     int64_t oidx;
@@ -377,13 +379,13 @@ __global__ __launch_bounds__(256, 3) void brats_march_pipe_kernel(const K1Args a
                 float tn = t + a.stepSize;
                 locate<STRICT>(a, ro, rd, tn, B.s);
                 B.issue(a);                                           // speculative next step
-                A.template consume<STRICT>(a, rd, r);
+                A.template consume<STRICT, GAMMA1>(a, rd, r);
                 t = tn;
                 if (!(t < t1 && r.T > a.ert)) break;
                 tn = t + a.stepSize;
                 locate<STRICT>(a, ro, rd, tn, A.s);
                 A.issue(a);
-                B.template consume<STRICT>(a, rd, r);
+                B.template consume<STRICT, GAMMA1>(a, rd, r);
                 t = tn;
                 if (!(t < t1 && r.T > a.ert)) break;
             }
@@ -395,7 +397,11 @@ __global__ __launch_bounds__(256, 3) void brats_march_pipe_kernel(const K1Args a
 template <bool STRICT, int LAYOUT, bool SHADE, int NCH>
 static int launch_pipe(const K1Args& a, hipStream_t s) {
     const dim3 grid(a.map.chunk * kXcds), block(a.map.blockPx == 8 ? 64 : 256);
-    hipLaunchKernelGGL((brats_march_pipe_kernel<STRICT, LAYOUT, SHADE, NCH>), grid, block, 0, s, a);
+    // the fp64 pow only matters for STRICT (FAST's is two instructions): specialise gamma == 1 there
+    if (STRICT && a.gamma == 1.0f)
+        hipLaunchKernelGGL((brats_march_pipe_kernel<STRICT, LAYOUT, SHADE, NCH, STRICT>), grid, block, 0, s, a);
+    else
+        hipLaunchKernelGGL((brats_march_pipe_kernel<STRICT, LAYOUT, SHADE, NCH, false>), grid, block, 0, s, a);
     MRIRT_HIP(hipGetLastError());
     return MRIRT_OK;
 }
