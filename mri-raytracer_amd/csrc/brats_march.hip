@@ -512,8 +512,11 @@ static int prepare(const MrirtBratsParams* p, const MrirtRenderExt* ext, const v
         if (p->showSeg != 0 && !labels) return MRIRT_ERR_NULL;
     }
     fill_camera(a.cam, p->eye, p->U, p->V, p->W, p->fovY, p->imageSize[0], p->imageSize[1], ext, false);
+    // XCD-interleaved bands of 16 px by default (variant bit 3: contiguous run per XCD; bits 4-5: 8/32/64 px)
+    const uint32_t bandSel = (variant >> 4) & 3u;
+    const uint32_t bandPx = (variant & 8u) ? 0u : (bandSel == 0 ? 16u : bandSel == 1 ? 8u : bandSel == 2 ? 32u : 64u);
     int rc = fill_pixel_map(a.map, p->imageSize[0], p->imageSize[1], pitch_px, ext,
-                            (variant & 2u) ? 16u : 8u, (variant & 1u) ? 0u : 1u);
+                            (variant & 2u) ? 16u : 8u, (variant & 1u) ? 0u : 1u, bandPx);
     if (rc != MRIRT_OK) return rc;
     fill_grid_dims(a.grid, p->dims, layout);
     fill_label_addr(a.lab, p->dims, labLayout);

@@ -175,6 +175,7 @@ struct PixelMap {
     uint32_t tileSize, tileRank, tileWorld, tilesX;   // tileSize == 0: whole frame
     uint32_t laneOrder;                // 0 row-major 8x8 packet, 1 Morton (2x2 pixel quads per 4 lanes)
     uint32_t blockPx;                  // 16: 256-thread workgroups (2x2 packets); 8: one packet per workgroup
+    uint32_t bandBlocks;               // whole-frame XCD interleave: workgroups per band (0 = contiguous runs)
     int64_t  pitch;                    // pixels per output row (whole-frame mode)
 };
 
@@ -185,7 +186,17 @@ struct PixelMap {
 // outIndex; 2: (tile mode) a compact-buffer slot outside the image: store background only.
 __device__ __forceinline__ int map_pixel(const PixelMap& m, uint32_t& px, uint32_t& py, int64_t& outIndex) {
     uint32_t b = blockIdx.x;
-    uint32_t logical = (b % kXcds) * m.chunk + b / kXcds;
+    uint32_t logical;
+    if (m.bandBlocks != 0) {
+        // whole frame: horizontal bands of bandBlocks workgroups (a few packet rows) dealt round-robin
+        // to the XCDs — XCD x marches bands x, x+8, x+16, ... so the mostly-empty top and bottom of
+        // the image are shared out, while each band is still a contiguous slab for one L2
+        const uint32_t xcd = b % kXcds, k = b / kXcds;
+        const uint32_t band = (k / m.bandBlocks) * kXcds + xcd;
+        logical = band * m.bandBlocks + k % m.bandBlocks;
+    } else {
+        logical = (b % kXcds) * m.chunk + b / kXcds;     // one contiguous run per XCD
+    }
     if (logical >= m.numBlocks) return 0;
     uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     uint32_t lx, ly;

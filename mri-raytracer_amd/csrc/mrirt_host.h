@@ -54,7 +54,7 @@ inline void fill_camera(Camera& c, const float eye[3], const float U[3], const f
 // returns MRIRT_OK or an error; grid size = map.chunk * 8 workgroups of 256 threads
 // blockPx: 16 (256-thread workgroups) or 8 (64-thread workgroups); laneOrder: see PixelMap
 inline int fill_pixel_map(PixelMap& m, uint32_t width, uint32_t height, int64_t pitch, const MrirtRenderExt* ext,
-                          uint32_t blockPx = kBlockPx, uint32_t laneOrder = 0) {
+                          uint32_t blockPx = kBlockPx, uint32_t laneOrder = 0, uint32_t bandPx = 0) {
     if (width == 0 || height == 0) return MRIRT_ERR_DIMS;
     m.width = width; m.height = height; m.pitch = pitch;
     m.tileSize = ext ? ext->tileSize : 0u;
@@ -76,6 +76,14 @@ inline int fill_pixel_map(PixelMap& m, uint32_t width, uint32_t height, int64_t 
         m.numBlocks = (uint32_t)local * bpr * bpr;
     }
     m.chunk = (m.numBlocks + kXcds - 1) / kXcds;
+    m.bandBlocks = 0;
+    if (m.tileSize == 0 && bandPx >= blockPx) {
+        // XCD-interleaved bands (see map_pixel): bandPx / blockPx workgroup rows per band
+        const uint32_t bandRows = bandPx / blockPx, blocksY = (height + blockPx - 1) / blockPx;
+        const uint32_t bands = (blocksY + bandRows - 1) / bandRows;
+        m.bandBlocks = m.blocksX * bandRows;
+        m.chunk = ((bands + kXcds - 1) / kXcds) * m.bandBlocks;
+    }
     return MRIRT_OK;
 }
 

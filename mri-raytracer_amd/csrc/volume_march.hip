@@ -173,7 +173,8 @@ extern "C" int mrirt_render_volume(const MrirtVolumeParams* p, const MrirtRender
     if (math > MRIRT_MATH_FAST || fmt > MRIRT_OUT_RGBA16F) return MRIRT_ERR_LAYOUT;
     K2Args a;
     fill_camera(a.cam, p->eye, p->U, p->V, p->W, p->fovY, p->imageSize[0], p->imageSize[1], ext, false);
-    int rc = fill_pixel_map(a.map, p->imageSize[0], p->imageSize[1], pitch_px, ext);
+    // 16x16-pixel workgroups, one workgroup row per band, bands interleaved over the XCDs (load balance)
+    int rc = fill_pixel_map(a.map, p->imageSize[0], p->imageSize[1], pitch_px, ext, kBlockPx, 0, kBlockPx);
     if (rc != MRIRT_OK) return rc;
     for (int k = 0; k < 3; ++k) { a.dim[k] = p->volDim[k]; a.dimM1[k] = (float)p->volDim[k] - 1.0f; }
     a.nearP = fmaxf(0.0f, p->nearPlane);
