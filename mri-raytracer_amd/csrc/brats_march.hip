@@ -200,7 +200,7 @@ __device__ __forceinline__ void fetch_labels(const K1Args& a, const Cell& s, Lab
 
 // GAMMA1: gamma == 1 (the viewer's constant, brats_viewer.py:422), where pow(val, 1) == val exactly;
 // compiling the fp64 pow out of the hot kernels frees the registers its temporaries would claim.
-template <bool STRICT, bool SHADE, bool GAMMA1 = false>
+template <bool STRICT, bool SHADE, bool GAMMA1 = false, bool LABELS = true>
 __device__ __forceinline__ void composite(const K1Args& a, const float rd[3], const Labels& lb, float v, const float g[3],
                                           RayState& r) {
     using Mm = M<STRICT>;
@@ -233,7 +233,7 @@ __device__ __forceinline__ void composite(const K1Args& a, const float rd[3], co
         r.C0 += c; r.C1 += c; r.C2 += c;
         r.T *= (1.0f - alpha);
     }
-    if (a.showSeg != 0) {                                            // :143-151
+    if (LABELS && a.showSeg != 0) {                                  // :143-151
         const uint32_t l = lb.seg;
         if (l > 0 && l < 8) {
             const float alpha = 1.0f - Mm::exp(-a.lut[l][3] * a.stepSize);
@@ -242,7 +242,7 @@ __device__ __forceinline__ void composite(const K1Args& a, const float rd[3], co
             r.T *= (1.0f - alpha);
         }
     }
-    if (a.showPred != 0) {                                           // :154-162
+    if (LABELS && a.showPred != 0) {                                 // :154-162
         const uint32_t l = lb.pred;
         if (l > 0 && l < 8) {
             const float alpha = 1.0f - Mm::exp(-a.lut[l][3] * a.stepSize * 1.5f);
@@ -332,7 +332,9 @@ __global__ __launch_bounds__(256) void brats_march_kernel(const K1Args a) {
 // intensities of every enabled modality plus the label fetches) are already in flight; the
 // compiler then waits with vmcnt(#gathers of one stage) instead of vmcnt(0).
 // ---------------------------------------------------------------------------------------
-template <int LAYOUT, bool SHADE, int NCH>
+// LABELS == false: neither overlay is shown, so the stage carries no label words and pIdx dies after
+// locate() — about ten VGPRs less across the two stages, which is what lets the kernel fit 4 waves/SIMD.
+template <int LAYOUT, bool SHADE, int NCH, bool LABELS>
 struct Stage {
     Cell s;
     Taps<LAYOUT, SHADE> taps[NCH];
@@ -340,7 +342,7 @@ struct Stage {
     __device__ __forceinline__ void issue(const K1Args& a) {
 #pragma unroll
         for (int c = 0; c < NCH; ++c) taps[c].issue(a.vol[a.chan[c]], a.grid, s);
-        fetch_labels(a, s, lb);
+        if constexpr (LABELS) fetch_labels(a, s, lb);
     }
     template <bool STRICT, bool GAMMA1>
     __device__ __forceinline__ void consume(const K1Args& a, const float rd[3], RayState& r) const {
@@ -357,12 +359,17 @@ struct Stage {
                 for (int k = 0; k < 3; ++k) g[k] = Mm::mad(gm[k], w, g[k]);
             }
         }
-        composite<STRICT, SHADE, GAMMA1>(a, rd, lb, v, g, r);
+        if constexpr (LABELS) {
+            composite<STRICT, SHADE, GAMMA1>(a, rd, lb, v, g, r);
+        } else {
+            const Labels none = { 0u, 0u };
+            composite<STRICT, SHADE, GAMMA1, false>(a, rd, none, v, g, r);
+        }
     }
 };
 
-template <bool STRICT, int LAYOUT, bool SHADE, int NCH, bool GAMMA1>
-__global__ __launch_bounds__(256, 3) void brats_march_pipe_kernel(const K1Args a) {
+template <bool STRICT, int LAYOUT, bool SHADE, int NCH, bool GAMMA1, bool LABELS>
+__global__ __launch_bounds__(256, LABELS ? 3 : 4) void brats_march_pipe_kernel(const K1Args a) {
     uint32_t px, py;
     int64_t oidx;
     const int kind = map_pixel(a.map, px, py, oidx);
@@ -371,7 +378,7 @@ __global__ __launch_bounds__(256, 3) void brats_march_pipe_kernel(const K1Args a
         float ro[3], rd[3], t0, t1;
         if (setup_ray(a, px, py, ro, rd, t0, t1) && t0 < t1 && 1.0f > a.ert) {   // the while-condition at entry
             float t = t0;
-            Stage<LAYOUT, SHADE, NCH> A, B;
+            Stage<LAYOUT, SHADE, NCH, LABELS> A, B;
             locate<STRICT>(a, ro, rd, t, A.s);
             A.issue(a);
             while (true) {
@@ -398,10 +405,14 @@ template <bool STRICT, int LAYOUT, bool SHADE, int NCH>
 static int launch_pipe(const K1Args& a, hipStream_t s) {
     const dim3 grid(a.map.chunk * kXcds), block(a.map.blockPx == 8 ? 64 : 256);
     // the fp64 pow only matters for STRICT (FAST's is two instructions): specialise gamma == 1 there
-    if (STRICT && a.gamma == 1.0f)
-        hipLaunchKernelGGL((brats_march_pipe_kernel<STRICT, LAYOUT, SHADE, NCH, STRICT>), grid, block, 0, s, a);
+    // ... and drop the label state when no overlay is shown (STRICT only: FAST already fits)
+    const bool overlays = a.showSeg != 0 || a.showPred != 0;
+    if (STRICT && a.gamma == 1.0f && !overlays)
+        hipLaunchKernelGGL((brats_march_pipe_kernel<STRICT, LAYOUT, SHADE, NCH, STRICT, !STRICT>), grid, block, 0, s, a);
+    else if (STRICT && a.gamma == 1.0f)
+        hipLaunchKernelGGL((brats_march_pipe_kernel<STRICT, LAYOUT, SHADE, NCH, STRICT, true>), grid, block, 0, s, a);
     else
-        hipLaunchKernelGGL((brats_march_pipe_kernel<STRICT, LAYOUT, SHADE, NCH, false>), grid, block, 0, s, a);
+        hipLaunchKernelGGL((brats_march_pipe_kernel<STRICT, LAYOUT, SHADE, NCH, false, true>), grid, block, 0, s, a);
     MRIRT_HIP(hipGetLastError());
     return MRIRT_OK;
 }
