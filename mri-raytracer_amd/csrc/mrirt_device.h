@@ -131,7 +131,46 @@ __device__ __forceinline__ void primary_ray(const Camera& c, uint32_t px, uint32
 struct GridDims {
     uint32_t X, Y, Z;
     uint32_t sY, sZ;       // LINEAR: X, X*Y.          BRICK: NBX*32, NBX*NBY*32
+    uint32_t wide;         // VG / QUAD: grid is >= 4 GiB, byte offsets need 64 bits
 };
+
+// VG / QUAD gathers: byte offsets of the 2x2x2 cell's corners.  The cell origin costs one
+// ox+oy+oz; its +1 neighbours are a per-axis delta (inside the brick, or across to the next one),
+// so the other seven corners are seven adds — and while the grid is < 4 GiB the offsets stay 32-bit
+// and go out as  global_load_dwordx4 v, voff, s[base]  with no 64-bit address arithmetic at all.
+struct CellOffsets {
+    uint32_t o, dx, dy, dz;    // float4 units
+};
+__device__ __forceinline__ CellOffsets vec4_cell(const GridDims& g, uint32_t ix, uint32_t iy, uint32_t iz) {
+    const uint32_t bx = ix & 1u, by = iy & 1u, bz = iz & 1u;
+    CellOffsets c;
+    c.o = (((ix >> 1) << 3) + bx) + ((iy >> 1) * g.sY + (by << 1)) + ((iz >> 1) * g.sZ + (bz << 2));
+    c.dx = bx ? 7u : 1u;                 // next brick (+8) and back to its x = 0 lane (-1)
+    c.dy = by ? g.sY - 2u : 2u;
+    c.dz = bz ? g.sZ - 4u : 4u;
+    return c;
+}
+template <bool WIDE> __device__ __forceinline__ float4 load_vec4(const void* __restrict__ base, uint32_t elem) {
+    const char* b = static_cast<const char*>(base);
+    if constexpr (WIDE) return *reinterpret_cast<const float4*>(b + ((uint64_t)elem << 4));
+    else return *reinterpret_cast<const float4*>(b + (uint32_t)(elem << 4));
+}
+
+// two fp32 lanes per instruction (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32): the x-y and z-w
+// halves of a float4 tap are already adjacent registers, so blending them as pairs needs no moves
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <bool STRICT> __device__ __forceinline__ f32x2 lerp2(f32x2 a, f32x2 b, float t) {
+    const f32x2 tt = { t, t };
+    if constexpr (STRICT) return a + tt * (b - a);               // unfused, element-wise as M<true>::lerp
+    else return __builtin_elementwise_fma(tt, b - a, a);
+}
+template <bool STRICT>
+__device__ __forceinline__ f32x2 trilerp2(f32x2 c000, f32x2 c100, f32x2 c010, f32x2 c110,
+                                          f32x2 c001, f32x2 c101, f32x2 c011, f32x2 c111,
+                                          float fx, float fy, float fz) {
+    return lerp2<STRICT>(lerp2<STRICT>(lerp2<STRICT>(c000, c100, fx), lerp2<STRICT>(c010, c110, fx), fy),
+                         lerp2<STRICT>(lerp2<STRICT>(c001, c101, fx), lerp2<STRICT>(c011, c111, fx), fy), fz);
+}
 
 template <int LAYOUT> struct Addr;
 template <> struct Addr<0> {

@@ -89,6 +89,9 @@ inline int fill_pixel_map(PixelMap& m, uint32_t width, uint32_t height, int64_t 
 
 inline void fill_grid_dims(GridDims& g, const uint32_t dims[3], uint32_t layout) {
     g.X = dims[0]; g.Y = dims[1]; g.Z = dims[2];
+    g.wide = 0;
+    if (layout == MRIRT_LAYOUT_VG || layout == MRIRT_LAYOUT_QUAD)
+        g.wide = ((uint64_t)mrirt_vec4_elems(dims) << 4) >= (1ull << 32) ? 1u : 0u;
     if (layout == MRIRT_LAYOUT_LINEAR) {
         g.sY = dims[0];
         g.sZ = dims[0] * dims[1];
