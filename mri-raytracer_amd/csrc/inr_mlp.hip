@@ -30,9 +30,11 @@ namespace mrirt {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <int N> struct IC { static constexpr int value = N; };   // compile-time int as a lambda argument
 
 constexpr int kInrWaves = 8;      // waves per workgroup
 constexpr int kMaxLayers = 8;
+constexpr int kPackSlackFrags = 64;   // one full chunk
 
 struct InrLayout {
     uint32_t numLayers, hidden, inDim, outDim, kt0;      // kt0: 32-wide k tiles of layer 0
@@ -41,6 +43,10 @@ struct InrLayout {
     uint32_t biasOff[kMaxLayers];                        // offset into the padded bias array
     uint32_t wOff[kMaxLayers];                           // offset into the unpadded fp32 weight array
     uint32_t totalFrags;
+    // Folded into the packed weights and the LDS copy of the biases, so that the activation is one
+    // instruction on the accumulator: SIREN layers are sin(2 pi . rev) with v_sin_f32 taking revolutions,
+    // hence scale = w0 / 2 pi (layer 0), 1 / 2 pi (hidden), 1 (head); ReLU nets: 1 everywhere.
+    float scale[kMaxLayers];
 };
 
 // Packed image, in fragment units:  layer 0: [o][t][s][hi,lo]   other layers: [o][t][s]
@@ -59,6 +65,8 @@ static int make_layout(const MrirtInrDesc* d, InrLayout& L) {
         L.out[l] = l + 1 == d->numLayers ? d->outDim : d->hidden;
         const uint32_t kt = l == 0 ? L.kt0 : d->hidden / 32, ot = (L.out[l] + 31) / 32;
         L.fragOff[l] = frag; L.biasOff[l] = bias; L.wOff[l] = w;
+        const bool sirenNet = d->kind == MRIRT_INR_SIREN || d->kind == 3u, head = l + 1 == d->numLayers;
+        L.scale[l] = (!sirenNet || head) ? 1.0f : (float)((l == 0 ? (double)d->w0 : 1.0) / 6.283185307179586);
         frag += ot * kt * 2 * (l == 0 ? 2 : 1);          // layer 0 stores hi and lo fragments side by side
         bias += ot * 32;
         w += L.in[l] * L.out[l];
@@ -88,7 +96,7 @@ __global__ __launch_bounds__(256) void inr_pack_kernel(const float* __restrict__
 #pragma unroll
     for (uint32_t j = 0; j < 8; ++j) {
         const uint32_t k = 32 * t + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3u), oc = 32 * o + r;
-        const float v = (k < L.in[l] && oc < L.out[l]) ? w[L.wOff[l] + k * L.out[l] + oc] : 0.0f;
+        const float v = (k < L.in[l] && oc < L.out[l]) ? w[L.wOff[l] + k * L.out[l] + oc] * L.scale[l] : 0.0f;
         const uint16_t hi = bf16_bits(v);
         const float hif = __builtin_bit_cast(float, (uint32_t)hi << 16);
         e[j] = lo ? bf16_bits(v - hif) : hi;
@@ -143,37 +151,57 @@ __global__ __launch_bounds__(512) void inr_forward_kernel(const InrArgs a) {
     constexpr int CH0 = OTC * F0, CHH = OTC * FH;        // fragments per chunk
     constexpr int CHMAX = CH0 > CHH ? CH0 : CHH;
     constexpr int PERW = (CHMAX + kInrWaves - 1) / kInrWaves;
+    constexpr int RD = 4;                                // A-fragment prefetch distance (ring of registers)
+    // DMA pieces of the NEXT chunk are dealt over the first three quarters of this chunk's k steps
+    constexpr int SP0 = (OTC * KT0 * 2 * 3 / 4) / PERW > 0 ? (OTC * KT0 * 2 * 3 / 4) / PERW : 1;
+    constexpr int SPH = (CHH * 3 / 4) / PERW > 0 ? (CHH * 3 / 4) / PERW : 1;
+    static_assert((PERW - 1) * SP0 < OTC * KT0 * 2 && (PERW - 1) * SPH < CHH, "every DMA piece must get a slot");
     constexpr int kBiasQ = kMaxLayers * 256 / 4;         // every layer's padded biases, as float4
     __shared__ uint4 ldsAll[2 * CHMAX * 64 + kBiasQ];    // 2 weight buffers (<= 64 KiB each) + biases: ONE LDS object (G17)
     uint4 (*lds)[CHMAX * 64] = reinterpret_cast<uint4 (*)[CHMAX * 64]>(ldsAll);
     const float4* ldsBias = reinterpret_cast<const float4*>(ldsAll + 2 * CHMAX * 64);
     {   // biases: global -> LDS once, so the loop's only vector-memory traffic is the weight LDS-DMA
         const uint32_t nq = (a.L.biasOff[a.L.numLayers - 1] + 32) / 4;
-        for (uint32_t i = threadIdx.x; i < nq; i += blockDim.x)
-            ldsAll[2 * CHMAX * 64 + i] = reinterpret_cast<const uint4*>(a.bias)[i];
+        for (uint32_t i = threadIdx.x; i < nq; i += blockDim.x) {
+            uint32_t l = 0;
+            while (l + 1 < a.L.numLayers && 4 * i >= a.L.biasOff[l + 1]) ++l;
+            float4 b = reinterpret_cast<const float4*>(a.bias)[i];
+            const float sc = a.L.scale[l];                      // same fold as the packed weights
+            b.x *= sc; b.y *= sc; b.z *= sc; b.w *= sc;
+            ldsAll[2 * CHMAX * 64 + i] = __builtin_bit_cast(uint4, b);
+        }
     }
 
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, r = lane & 31u, h = lane >> 5;
     const int64_t base = ((int64_t)blockIdx.x * kInrWaves + wave) * 32;
     const uint4* __restrict__ wp = a.wpack;
+    const uint32_t waveS = __builtin_amdgcn_readfirstlane(wave);
     constexpr bool siren = SIREN;                        // sin activations (kinds 1, 3) vs ReLU (kinds 0, 2)
 
     // ---- chunk streaming: LDS-DMA, one 1-KiB fragment per wave-instruction (lane-linear image) -----------
-    auto stage_issue = [&](uint32_t fragStart, int nfrag, int dstBuf) {
+    // piece i of this wave = fragment wave + 8 i of the chunk.  A DMA instruction costs its wave tens of
+    // issue cycles, so inside the MFMA streams the pieces are dealt out one every few k steps (the other
+    // wave of the SIMD keeps the matrix core busy meanwhile) instead of eight in a row at the chunk's start.
+    // The fragment count is a compile-time constant (a chunk that is followed by the short head chunk
+    // fetches a full hidden chunk: the packed image carries that much slack, mrirt_inr_pack_bytes), so
+    // with 8 | N the piece is unconditional and the MFMA stream stays one basic block.
+    auto stage_piece = [&](uint32_t fragStart, auto nfragC, int dstBuf, int i) {
+        constexpr int N = decltype(nfragC)::value;
+        const int f = (int)waveS + i * kInrWaves;                    // scalar: the source is s[base] + lane * 16
+        if ((N % kInrWaves == 0) ? (i < N / kInrWaves) : (f < N))
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(wp) + ((size_t)(fragStart + f) << 10) + (lane << 4)),
+                (__attribute__((address_space(3))) void*)(&lds[dstBuf][f * 64]), 16, 0, 0);
+    };
+    auto stage_issue = [&](uint32_t fragStart, auto nfragC, int dstBuf) {
 #pragma unroll
-        for (int i = 0; i < PERW; ++i) {
-            const int f = (int)wave + i * kInrWaves;                 // wave-uniform
-            if (f < nfrag)
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void*)(wp + (size_t)(fragStart + f) * 64 + lane),
-                    (__attribute__((address_space(3))) void*)(&lds[dstBuf][f * 64]), 16, 0, 0);
-        }
+        for (int i = 0; i < PERW; ++i) stage_piece(fragStart, nfragC, dstBuf, i);
     };
     auto frag_at = [&](int buf, int f) { return __builtin_bit_cast(bf16x8, lds[buf][f * 64 + lane]); };
 
     uint32_t nextFrag = a.L.fragOff[0];
     int buf = 0;
-    stage_issue(nextFrag, CH0, 0);
+    stage_issue(nextFrag, IC<CH0>{}, 0);
     nextFrag += CH0;
 
     // ---- layer-0 B operands: this lane's point, features 16s + 8(j>>2) + 4h + (j&3) of k tile t --------
@@ -209,26 +237,30 @@ __global__ __launch_bounds__(512) void inr_forward_kernel(const InrArgs a) {
     bf16x8 Hn[KT][2];            // next layer's input, built out tile by out tile
 
     // bias of out tile o for this lane half: rows 8g + 4h .. +3 (g = 0..3) = four aligned float4
-    auto load_bias = [&](uint32_t layerOff, int o, float4 b4[4]) {       // from the LDS copy (ds_read_b128)
+    // The accumulator STARTS at the bias (accumulator register i holds row (i&3) + 8(i>>2) + 4h, i.e. the
+    // four aligned float4 at rows 8g + 4h of the LDS copy), so no add is left for the activation.
+    auto bias_tile = [&](uint32_t layerOff, int o) {                     // ds_read_b128 x 4
+        f32x16 acc;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) b4[g] = ldsBias[(layerOff + 32 * o + 8 * g + 4 * h) >> 2];
+        for (int g = 0; g < 4; ++g) {
+            const float4 b = ldsBias[(layerOff + 32 * o + 8 * g + 4 * h) >> 2];
+            acc[4 * g + 0] = b.x; acc[4 * g + 1] = b.y; acc[4 * g + 2] = b.z; acc[4 * g + 3] = b.w;
+        }
+        return acc;
     };
-    auto activate = [&](const f32x16& acc, const float4 b4[4], int o, bool first) {
+    // one instruction per value (v_sin_f32 on revolutions: the 1/2pi and w0 are folded into the weights;
+    // neumors_inr.ipynb:1165-1178) or half of one (v_pk_max_f32; model.py:46-48), plus the packed bf16 convert
+    auto activate = [&](const f32x16& acc, int o) {
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int i = 8 * s + j;                 // accumulator register i holds row (i&3) + 8(i>>2) + 4h
-                const float4 bq = b4[i >> 2];
-                const float b = (i & 3) == 0 ? bq.x : (i & 3) == 1 ? bq.y : (i & 3) == 2 ? bq.z : bq.w;
-                float x = acc[i];
-                if (siren) {                             // neumors_inr.ipynb:1165-1178; v_sin_f32 takes revolutions
-                    x = (first ? a.w0 * x : x) + b;
-                    x = __builtin_amdgcn_sinf(x * 0.15915494309189535f);
-                } else {
-                    x = fmaxf(x + b, 0.0f);              // model.py:46-48
-                }
-                Hn[o][s][j] = (__bf16)x;
+            for (int j = 0; j < 8; j += 2) {
+                const int i = 8 * s + j;
+                f32x2 x = { acc[i], acc[i + 1] };
+                if (siren) { x.x = __builtin_amdgcn_sinf(x.x); x.y = __builtin_amdgcn_sinf(x.y); }
+                else x = __builtin_elementwise_max(x, (f32x2){ 0.0f, 0.0f });
+                Hn[o][s][j] = (__bf16)x.x;
+                Hn[o][s][j + 1] = (__bf16)x.y;
             }
     };
     // the chunk prefetched during this chunk's compute becomes current (hipcc drains the LDS-DMA
@@ -241,23 +273,28 @@ __global__ __launch_bounds__(512) void inr_forward_kernel(const InrArgs a) {
 #pragma unroll
         for (int og = 0; og < KT / OTC; ++og) {
             const int nfragNext = (og + 1 < KT / OTC) ? CH0 : (a.L.numLayers > 2 ? CHH : FH);   // layer 0 / layer 1 / head
-            stage_issue(nextFrag, nfragNext, buf ^ 1);
+            bf16x8 ring[RD];                             // fragment stream: even = hi, odd = lo of k step f/2
+#pragma unroll
+            for (int d = 0; d < RD; ++d) if (d < CH0) ring[d] = frag_at(buf, d);
 #pragma unroll
             for (int oo = 0; oo < OTC; ++oo) {
                 const int o = og * OTC + oo;
-                float4 b4[4];
-                load_bias(b0, o, b4);
-                f32x16 acc = (f32x16)(0.0f);
+                f32x16 acc = bias_tile(b0, o);
 #pragma unroll
-                for (int t = 0; t < KT0; ++t)
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        const bf16x8 whi = frag_at(buf, oo * F0 + (t * 2 + s) * 2), wlo = frag_at(buf, oo * F0 + (t * 2 + s) * 2 + 1);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo, xin_hi[t][s], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi, xin_lo[t][s], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi, xin_hi[t][s], acc, 0, 0, 0);
+                for (int p = 0; p < KT0 * 2; ++p) {
+                    const int t = p >> 1, s = p & 1, f = oo * F0 + 2 * p, step = oo * KT0 * 2 + p;
+                    if (step % SP0 == 0 && step / SP0 < PERW) {
+                        if (og + 1 < KT / OTC) stage_piece(nextFrag, IC<CH0>{}, buf ^ 1, step / SP0);    // folds: og is unrolled
+                        else                   stage_piece(nextFrag, IC<CHH>{}, buf ^ 1, step / SP0);
                     }
-                activate(acc, b4, o, true);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[(f + 1) % RD], xin_hi[t][s], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[f % RD], xin_lo[t][s], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[f % RD], xin_hi[t][s], acc, 0, 0, 0);
+                    if (f + RD < CH0) ring[f % RD] = frag_at(buf, f + RD);
+                    if (f + 1 + RD < CH0) ring[(f + 1) % RD] = frag_at(buf, f + 1 + RD);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                activate(acc, o);
             }
             next_chunk();
             nextFrag += nfragNext;
@@ -273,19 +310,24 @@ __global__ __launch_bounds__(512) void inr_forward_kernel(const InrArgs a) {
 #pragma unroll
         for (int og = 0; og < KT / OTC; ++og) {
             const int nfragNext = (og + 1 < KT / OTC || !lastHidden) ? CHH : FH;    // more hidden tiles, or the head
-            stage_issue(nextFrag, nfragNext, buf ^ 1);
+            // A fragments run RD ahead of the MFMA that consumes them (the chunk is one fragment stream,
+            // so the prefetch carries across out tiles): an LDS read is ~4 MFMA issue slots of latency
+            bf16x8 ring[RD];
+#pragma unroll
+            for (int d = 0; d < RD; ++d) if (d < CHH) ring[d] = frag_at(buf, d);
 #pragma unroll
             for (int oo = 0; oo < OTC; ++oo) {
                 const int o = og * OTC + oo;
-                float4 b4[4];
-                load_bias(bl, o, b4);
-                f32x16 acc = (f32x16)(0.0f);
+                f32x16 acc = bias_tile(bl, o);
 #pragma unroll
-                for (int t = 0; t < KT; ++t)
-#pragma unroll
-                    for (int s = 0; s < 2; ++s)
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_at(buf, oo * FH + t * 2 + s), Hc[t][s], acc, 0, 0, 0);
-                activate(acc, b4, o, false);
+                for (int ts = 0; ts < FH; ++ts) {
+                    const int f = oo * FH + ts;
+                    if (f % SPH == 0 && f / SPH < PERW) stage_piece(nextFrag, IC<CHH>{}, buf ^ 1, f / SPH);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[f % RD], Hc[ts >> 1][ts & 1], acc, 0, 0, 0);
+                    if (f + RD < CHH) ring[f % RD] = frag_at(buf, f + RD);
+                    __builtin_amdgcn_sched_barrier(0);   // keep the refill RD steps ahead (the scheduler would sink it)
+                }
+                activate(acc, o);
             }
             next_chunk();
             nextFrag += nfragNext;
@@ -294,20 +336,23 @@ __global__ __launch_bounds__(512) void inr_forward_kernel(const InrArgs a) {
 
     // ---- head: one out tile (outDim <= 16 rows used), linear ---------------------------------------------------
     {
-        const float* __restrict__ bl = a.bias + a.L.biasOff[a.L.numLayers - 1];
-        f32x16 acc = (f32x16)(0.0f);
+        f32x16 acc = bias_tile(a.L.biasOff[a.L.numLayers - 1], 0);      // rows >= outDim: zero padding
+        bf16x8 ring[RD];
 #pragma unroll
-        for (int t = 0; t < KT; ++t)
+        for (int d = 0; d < RD; ++d) if (d < FH) ring[d] = frag_at(buf, d);
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_at(buf, t * 2 + s), Hn[t][s], acc, 0, 0, 0);
+        for (int f = 0; f < FH; ++f) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[f % RD], Hn[f >> 1][f & 1], acc, 0, 0, 0);
+            if (f + RD < FH) ring[f % RD] = frag_at(buf, f + RD);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         float best = -INFINITY;
         uint32_t bestc = 0xffffu;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const uint32_t cls = (i & 3) + 8 * (i >> 2) + 4 * h;
             if (cls < a.L.outDim) {
-                const float v = acc[i] + bl[cls];
+                const float v = acc[i];
                 if (a.logits && pidx < a.n) a.logits[pidx * a.L.outDim + cls] = v;
                 if (v > best || (v == best && cls < bestc)) { best = v; bestc = cls; }    // np.argmax: first maximum
             }
@@ -365,7 +410,7 @@ using namespace mrirt;
 extern "C" int64_t mrirt_inr_pack_bytes(const MrirtInrDesc* desc) {
     InrLayout L;
     if (make_layout(desc, L) != MRIRT_OK) return 0;
-    return (int64_t)L.totalFrags * 1024;
+    return (int64_t)(L.totalFrags + kPackSlackFrags) * 1024;    // slack: the last chunk's DMA over-fetch (never used)
 }
 
 extern "C" int mrirt_inr_pack_weights(const MrirtInrDesc* desc, const float* w_f32, void* packed, void* stream) {
