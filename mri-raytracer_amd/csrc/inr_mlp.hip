@@ -155,6 +155,7 @@ __global__ __launch_bounds__(512) void inr_forward_kernel(const InrArgs a) {
     // DMA pieces of the NEXT chunk are dealt over the first three quarters of this chunk's k steps
     constexpr int SP0 = (OTC * KT0 * 2 * 3 / 4) / PERW > 0 ? (OTC * KT0 * 2 * 3 / 4) / PERW : 1;
     constexpr int SPH = (CHH * 3 / 4) / PERW > 0 ? (CHH * 3 / 4) / PERW : 1;
+    constexpr int PPT = (PERW + OTC - 1) / OTC;          // hidden layers: pieces per out tile
     static_assert((PERW - 1) * SP0 < OTC * KT0 * 2 && (PERW - 1) * SPH < CHH, "every DMA piece must get a slot");
     constexpr int kBiasQ = kMaxLayers * 256 / 4;         // every layer's padded biases, as float4
     __shared__ uint4 ldsAll[2 * CHMAX * 64 + kBiasQ];    // 2 weight buffers (<= 64 KiB each) + biases: ONE LDS object (G17)
@@ -241,6 +242,9 @@ __global__ __launch_bounds__(512) void inr_forward_kernel(const InrArgs a) {
     // four aligned float4 at rows 8g + 4h of the LDS copy), so no add is left for the activation.
     auto bias_tile = [&](uint32_t layerOff, int o) {                     // ds_read_b128 x 4
         f32x16 acc;
+#ifdef MRIRT_EXP_NOBIAS
+        return (f32x16)(0.0f);
+#endif
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const float4 b = ldsBias[(layerOff + 32 * o + 8 * g + 4 * h) >> 2];
@@ -262,6 +266,24 @@ __global__ __launch_bounds__(512) void inr_forward_kernel(const InrArgs a) {
                 Hn[o][s][j] = (__bf16)x.x;
                 Hn[o][s][j + 1] = (__bf16)x.y;
             }
+    };
+    // The same activation, one slice per k step of the NEXT out tile.  The two waves of a SIMD leave the
+    // chunk barrier in phase; with whole-tile activation they would both be in their VALU phase at once
+    // and the matrix core would idle (measured: MFMA-busy + VALU cycles == kernel cycles).  Sliced under
+    // the next tile's MFMAs, a v_sin_f32 (16 cycles) fits inside each MFMA's 32.
+    auto act_slice = [&](f32x16& ap, int o, int step, auto nstepsC) {
+        constexpr int NS = decltype(nstepsC)::value, PER = 16 / NS;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int i = step * PER + q;
+            if (siren) ap[i] = __builtin_amdgcn_sinf(ap[i]);
+            if (i & 1) {
+                f32x2 x = { ap[i - 1], ap[i] };
+                if (!siren) x = __builtin_elementwise_max(x, (f32x2){ 0.0f, 0.0f });
+                Hn[o][i >> 3][(i & 7) - 1] = (__bf16)x.x;
+                Hn[o][i >> 3][i & 7] = (__bf16)x.y;
+            }
+        }
     };
     // the chunk prefetched during this chunk's compute becomes current (hipcc drains the LDS-DMA
     // with vmcnt(0) at the barrier)
@@ -307,6 +329,7 @@ __global__ __launch_bounds__(512) void inr_forward_kernel(const InrArgs a) {
         for (int t = 0; t < KT; ++t) { Hc[t][0] = Hn[t][0]; Hc[t][1] = Hn[t][1]; }
         const uint32_t bl = a.L.biasOff[l];
         const bool lastHidden = l + 2 == a.L.numLayers;
+        f32x16 accPrev;                                  // finished tile o - 1, activated under tile o's MFMAs
 #pragma unroll
         for (int og = 0; og < KT / OTC; ++og) {
             const int nfragNext = (og + 1 < KT / OTC || !lastHidden) ? CHH : FH;    // more hidden tiles, or the head
@@ -322,16 +345,25 @@ __global__ __launch_bounds__(512) void inr_forward_kernel(const InrArgs a) {
 #pragma unroll
                 for (int ts = 0; ts < FH; ++ts) {
                     const int f = oo * FH + ts;
-                    if (f % SPH == 0 && f / SPH < PERW) stage_piece(nextFrag, IC<CHH>{}, buf ^ 1, f / SPH);
+                    // right after the tile's bias read: hipcc makes any LDS read it cannot tell apart from the
+                    // DMA target wait vmcnt(0), so a piece still in flight at the next tile's bias read stalls it
+                    if constexpr (FH > PPT) {
+                        if (ts >= 1 && ts <= PPT && oo * PPT + ts - 1 < PERW) stage_piece(nextFrag, IC<CHH>{}, buf ^ 1, oo * PPT + ts - 1);
+                    } else {
+                        if (f % SPH == 0 && f / SPH < PERW) stage_piece(nextFrag, IC<CHH>{}, buf ^ 1, f / SPH);
+                    }
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[f % RD], Hc[ts >> 1][ts & 1], acc, 0, 0, 0);
                     if (f + RD < CHH) ring[f % RD] = frag_at(buf, f + RD);
+                    if (o > 0) act_slice(accPrev, o - 1, ts, IC<FH>{});
                     __builtin_amdgcn_sched_barrier(0);   // keep the refill RD steps ahead (the scheduler would sink it)
                 }
-                activate(acc, o);
+                accPrev = acc;
             }
             next_chunk();
             nextFrag += nfragNext;
         }
+#pragma unroll
+        for (int ts = 0; ts < FH; ++ts) act_slice(accPrev, KT - 1, ts, IC<FH>{});     // the layer's last tile
     }
 
     // ---- head: one out tile (outDim <= 16 rows used), linear ---------------------------------------------------
