@@ -35,6 +35,8 @@ template <int N> struct IC { static constexpr int value = N; };   // compile-tim
 constexpr int kInrWaves = 8;      // waves per workgroup
 constexpr int kMaxLayers = 8;
 constexpr int kPackSlackFrags = 64;   // one full chunk
+constexpr int kRawStride = 12;        // floats per point in the LDS copy of the raw inputs: c0..c2, m0..m7, 0
+constexpr int kMaxMods = 8;
 
 struct InrLayout {
     uint32_t numLayers, hidden, inDim, outDim, kt0;      // kt0: 32-wide k tiles of layer 0
@@ -57,6 +59,7 @@ static int make_layout(const MrirtInrDesc* d, InrLayout& L) {
     if (d->inDim < 1 || d->inDim > 128 || d->kind > 3) return MRIRT_ERR_ARG;
     if (d->kind == MRIRT_INR_FOURIER_RELU && d->inDim != 3 + 6 * d->fourierFreqs + d->numMods) return MRIRT_ERR_ARG;
     if (d->kind == MRIRT_INR_SIREN && d->inDim != 3 + d->numMods) return MRIRT_ERR_ARG;
+    if (d->kind < 2 && d->numMods > (uint32_t)kMaxMods) return MRIRT_ERR_ARG;    // raw inputs are staged 12 floats per point
     L.numLayers = d->numLayers; L.hidden = d->hidden; L.inDim = d->inDim; L.outDim = d->outDim;
     L.kt0 = d->inDim <= 32 ? 1 : 4;                      // 33..128 inputs: zero-padded to 128 (layer 0 only)
     uint32_t frag = 0, bias = 0, w = 0;
@@ -122,27 +125,6 @@ struct InrArgs {
     int16_t* argmax;
 };
 
-// value of input feature f for point p (inr/inr/model.py:11-23 feature order)
-__device__ __forceinline__ float input_feature(const InrArgs& a, uint32_t f, int64_t p, const float c[3]) {
-    if (f >= a.L.inDim) return 0.0f;
-    const bool raw = a.kind >= 2;
-    const uint32_t nc = raw ? 0u : 3u;
-    if (f < nc) return c[f];
-    uint32_t g = f - nc;
-    if (a.kind == MRIRT_INR_FOURIER_RELU) {
-        if (g < 6 * a.K) {
-            const uint32_t axis = g / (2 * a.K), rem = g % (2 * a.K);
-            const bool isSin = rem < a.K;
-            // sin(pi k c) / cos(pi k c): v_sin_f32 / v_cos_f32 take revolutions, k c / 2 (|.| <= 8 at K = 16);
-            // their ~1e-6 absolute error is far below the split-bf16 resolution of the layer-0 operands
-            const float rev = (c[axis] * (float)((isSin ? rem : rem - a.K) + 1)) * 0.5f;
-            return isSin ? __builtin_amdgcn_sinf(rev) : __builtin_amdgcn_cosf(rev);
-        }
-        g -= 6 * a.K;
-    }
-    return a.volume ? a.feats[(size_t)g * ((size_t)a.H * a.W * a.D) + p] : a.feats[p * (int64_t)a.M + g];
-}
-
 template <int HID, int KT0, bool SIREN>
 __global__ __launch_bounds__(512) void inr_forward_kernel(const InrArgs a) {
     constexpr int KT = HID / 32;                         // k tiles of a hidden-wide input == out tiles of a hidden-wide output
@@ -158,9 +140,39 @@ __global__ __launch_bounds__(512) void inr_forward_kernel(const InrArgs a) {
     constexpr int PPT = (PERW + OTC - 1) / OTC;          // hidden layers: pieces per out tile
     static_assert((PERW - 1) * SP0 < OTC * KT0 * 2 && (PERW - 1) * SPH < CHH, "every DMA piece must get a slot");
     constexpr int kBiasQ = kMaxLayers * 256 / 4;         // every layer's padded biases, as float4
-    __shared__ uint4 ldsAll[2 * CHMAX * 64 + kBiasQ];    // 2 weight buffers (<= 64 KiB each) + biases: ONE LDS object (G17)
+    constexpr int kTabQ = 128;                           // one descriptor per layer-0 input feature
+    constexpr int kRawQ = kInrWaves * 32 * kRawStride / 4;   // each wave's 32 points x (3 coords, <= 8 mods, a zero)
+    // 2 weight buffers (<= 64 KiB each) + biases + feature table + raw inputs: ONE LDS object (G17)
+    __shared__ uint4 ldsAll[2 * CHMAX * 64 + kBiasQ + kTabQ + kRawQ];
     uint4 (*lds)[CHMAX * 64] = reinterpret_cast<uint4 (*)[CHMAX * 64]>(ldsAll);
     const float4* ldsBias = reinterpret_cast<const float4*>(ldsAll + 2 * CHMAX * 64);
+    float4* ldsTab = reinterpret_cast<float4*>(ldsAll + 2 * CHMAX * 64 + kBiasQ);
+    float* ldsRaw = reinterpret_cast<float*>(ldsAll + 2 * CHMAX * 64 + kBiasQ + kTabQ);
+    // Feature table (inr/inr/model.py:11-23 order: coords, per axis [sin k=1..K, cos k=1..K], modalities):
+    // feature f of a point is  trig ? sin(2 pi (raw[src] * mult + phase)) : raw[src]  with raw = (c0,c1,c2,
+    // m0..m7, 0).  sin(pi k c) / cos(pi k c) go through v_sin_f32, which takes revolutions: mult = k/2
+    // (|.| <= 8 at K = 16), phase 0 / 0.25; its ~1e-6 absolute error is far below the split-bf16
+    // resolution of the layer-0 operands.
+    if (a.kind < 2 && threadIdx.x < 128) {
+        const uint32_t f = threadIdx.x;
+        uint32_t src = kRawStride - 1, trig = 0;
+        float mult = 0.0f, phase = 0.0f;
+        if (f < 3) src = f;
+        else if (f < a.L.inDim) {
+            uint32_t g = f - 3;
+            if (a.kind == MRIRT_INR_FOURIER_RELU && g < 6 * a.K) {
+                const uint32_t axis = g / (2 * a.K), rem = g % (2 * a.K);
+                const bool isSin = rem < a.K;
+                src = axis; trig = 1;
+                mult = (float)((isSin ? rem : rem - a.K) + 1) * 0.5f;
+                phase = isSin ? 0.0f : 0.25f;
+            } else {
+                if (a.kind == MRIRT_INR_FOURIER_RELU) g -= 6 * a.K;
+                src = 3 + g;
+            }
+        }
+        ldsTab[f] = make_float4(mult, phase, __builtin_bit_cast(float, src), __builtin_bit_cast(float, trig));
+    }
     {   // biases: global -> LDS once, so the loop's only vector-memory traffic is the weight LDS-DMA
         const uint32_t nq = (a.L.biasOff[a.L.numLayers - 1] + 32) / 4;
         for (uint32_t i = threadIdx.x; i < nq; i += blockDim.x) {
@@ -173,8 +185,10 @@ __global__ __launch_bounds__(512) void inr_forward_kernel(const InrArgs a) {
         }
     }
 
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, r = lane & 31u, h = lane >> 5;
-    const int64_t base = ((int64_t)blockIdx.x * kInrWaves + wave) * 32;
+    // lane / r / h are re-derived (opaquely) at the top of every batch: addresses computed from a
+    // loop-invariant lane id would be hoisted out of the batch loop and spilled around it
+    uint32_t lane = threadIdx.x & 63u, r = lane & 31u, h = lane >> 5;
+    const uint32_t wave = threadIdx.x >> 6;
     const uint4* __restrict__ wp = a.wpack;
     const uint32_t waveS = __builtin_amdgcn_readfirstlane(wave);
     constexpr bool siren = SIREN;                        // sin activations (kinds 1, 3) vs ReLU (kinds 0, 2)
@@ -205,34 +219,81 @@ __global__ __launch_bounds__(512) void inr_forward_kernel(const InrArgs a) {
     stage_issue(nextFrag, IC<CH0>{}, 0);
     nextFrag += CH0;
 
-    // ---- layer-0 B operands: this lane's point, features 16s + 8(j>>2) + 4h + (j&3) of k tile t --------
+    // layer-0 B operands: this lane's point, features 16s + 8(j>>2) + 4h + (j&3) of k tile t
     bf16x8 xin_hi[KT0][2], xin_lo[KT0][2];
-    const int64_t pidx = base + r;
-    {
-        int64_t p = pidx < a.n ? pidx : a.n - 1;         // clamp: compute something, store nothing
-        float c[3] = { 0.0f, 0.0f, 0.0f };
-        if (a.volume) {                                  // model.py:124-128, fp64 then one rounding to fp32
-            const uint32_t k = (uint32_t)(p % a.D), j = (uint32_t)((p / a.D) % a.W), i = (uint32_t)(p / ((int64_t)a.D * a.W));
-            c[0] = (float)(((double)i / (double)(a.H - 1)) * 2.0 - 1.0);
-            c[1] = (float)(((double)j / (double)(a.W - 1)) * 2.0 - 1.0);
-            c[2] = (float)(((double)k / (double)(a.D - 1)) * 2.0 - 1.0);
-        } else if (a.coords) {
-            c[0] = a.coords[p * 3 + 0]; c[1] = a.coords[p * 3 + 1]; c[2] = a.coords[p * 3 + 2];
-        }
+    // Every load below is unconditional and straight-line (clamped index, value masked afterwards): a load
+    // inside a per-feature branch makes hipcc wait vmcnt(0) per feature — one memory round trip each.
+    auto load_inputs = [&](int64_t pidx) {
+        const int64_t p = pidx < a.n ? pidx : a.n - 1;   // clamp: compute something, store nothing
+        if (a.kind < 2) {
+            // lane half 0 stages its point's raw inputs (3 coords + <= 8 modalities + a zero) in LDS ...
+            float* raw = ldsRaw + (waveS * 32 + r) * kRawStride;
+            if (h == 0) {
+                float c[3], m[kMaxMods];
+                const uint32_t M = a.M;
+                if (a.volume) {                          // model.py:124-128, fp64 then one rounding to fp32
+                    const uint32_t k = (uint32_t)(p % a.D), j = (uint32_t)((p / a.D) % a.W), i = (uint32_t)(p / ((int64_t)a.D * a.W));
+                    c[0] = (float)(((double)i / (double)(a.H - 1)) * 2.0 - 1.0);
+                    c[1] = (float)(((double)j / (double)(a.W - 1)) * 2.0 - 1.0);
+                    c[2] = (float)(((double)k / (double)(a.D - 1)) * 2.0 - 1.0);
+                    const size_t hwd = (size_t)a.H * a.W * a.D;
 #pragma unroll
-        for (int t = 0; t < KT0; ++t)
+                    for (uint32_t g = 0; g < kMaxMods; ++g) m[g] = M ? a.feats[(size_t)(g < M ? g : M - 1) * hwd + p] : 0.0f;
+                } else {
+                    c[0] = a.coords[p * 3 + 0]; c[1] = a.coords[p * 3 + 1]; c[2] = a.coords[p * 3 + 2];
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const uint32_t f = 32 * t + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3);
-                    const float v = input_feature(a, f, p, c);
-                    const __bf16 hi = (__bf16)v;
-                    xin_hi[t][s][j] = hi;
-                    xin_lo[t][s][j] = (__bf16)(v - (float)hi);
+                    for (uint32_t g = 0; g < kMaxMods; ++g) m[g] = M ? a.feats[p * (int64_t)M + (g < M ? g : M - 1)] : 0.0f;
                 }
-    }
-    __syncthreads();                                     // chunk 0 is in LDS
+                float4* rq = reinterpret_cast<float4*>(raw);
+                rq[0] = make_float4(c[0], c[1], c[2], m[0]);
+                rq[1] = make_float4(m[1], m[2], m[3], m[4]);
+                rq[2] = make_float4(m[5], m[6], m[7], 0.0f);
+            }
+            // ... and both halves build their features from the table (same wave: LDS ops are in order)
+            // (eight descriptors, then eight raw values, then the arithmetic: two LDS latencies per k step
+            // instead of two per feature)
+#pragma unroll
+            for (int t = 0; t < KT0; ++t)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    float4 d[8];
+                    float x[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) d[j] = ldsTab[32 * t + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3)];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) x[j] = raw[__builtin_bit_cast(uint32_t, d[j].z)];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float v = __builtin_bit_cast(uint32_t, d[j].w) ? __builtin_amdgcn_sinf(__builtin_fmaf(x[j], d[j].x, d[j].y)) : x[j];
+                        const __bf16 hi = (__bf16)v;
+                        xin_hi[t][s][j] = hi;
+                        xin_lo[t][s][j] = (__bf16)(v - (float)hi);
+                    }
+                }
+        } else {
+            // raw-x kinds (tests, other front ends): feats IS the [n][inDim] input matrix
+#pragma unroll
+            for (int t = 0; t < KT0; ++t)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const uint32_t f = 32 * t + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3);
+                        v[j] = a.feats[p * (int64_t)a.L.inDim + (f < a.L.inDim ? f : 0u)];
+                        v[j] = f < a.L.inDim ? v[j] : 0.0f;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const __bf16 hi = (__bf16)v[j];
+                        xin_hi[t][s][j] = hi;
+                        xin_lo[t][s][j] = (__bf16)(v[j] - (float)hi);
+                    }
+                }
+        }
+    };
 
     bf16x8 Hc[KT][2];            // current layer's input, as B operands
     bf16x8 Hn[KT][2];            // next layer's input, built out tile by out tile
@@ -288,6 +349,21 @@ __global__ __launch_bounds__(512) void inr_forward_kernel(const InrArgs a) {
     // the chunk prefetched during this chunk's compute becomes current (hipcc drains the LDS-DMA
     // with vmcnt(0) at the barrier)
     auto next_chunk = [&]() { __syncthreads(); buf ^= 1; };
+
+    __syncthreads();                                     // biases and layer-0 chunk 0 are in LDS
+
+    // Persistent workgroup: batches of 256 points, round-robin.  The weight stream is cyclic — the head
+    // chunk stages layer 0's first chunk of the NEXT batch — so after the first batch no DMA latency,
+    // workgroup launch or bias staging is exposed.
+    const int64_t nBatches = (a.n + kInrWaves * 32 - 1) / (kInrWaves * 32);
+    int64_t pendIdx = -1;
+    int16_t pendVal = 0;
+    for (int64_t batch = blockIdx.x; batch < nBatches; batch += gridDim.x) {
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+    r = lane & 31u; h = lane >> 5;
+    if (pendIdx >= 0) a.argmax[pendIdx] = pendVal;       // the previous batch's classes
+    const int64_t pidx = (batch * kInrWaves + waveS) * 32 + r;
+    load_inputs(pidx);
 
     // ---- layer 0: hi/lo split, three products per k step -------------------------------------------------
     {
@@ -369,6 +445,7 @@ __global__ __launch_bounds__(512) void inr_forward_kernel(const InrArgs a) {
     // ---- head: one out tile (outDim <= 16 rows used), linear ---------------------------------------------------
     {
         f32x16 acc = bias_tile(a.L.biasOff[a.L.numLayers - 1], 0);      // rows >= outDim: zero padding
+        stage_issue(a.L.fragOff[0], IC<CH0>{}, buf ^ 1);                 // the next batch's first chunk
         bf16x8 ring[RD];
 #pragma unroll
         for (int d = 0; d < RD; ++d) if (d < FH) ring[d] = frag_at(buf, d);
@@ -378,36 +455,58 @@ __global__ __launch_bounds__(512) void inr_forward_kernel(const InrArgs a) {
             if (f + RD < FH) ring[f % RD] = frag_at(buf, f + RD);
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (a.logits != nullptr && pidx < a.n) {         // uniform pointer test; not the throughput path
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const uint32_t cls = (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (cls < a.L.outDim) a.logits[pidx * a.L.outDim + cls] = acc[i];
+            }
+        }
+        // np.argmax = first maximum.  Within a lane cls grows with i, so a strict > keeps the first; the
+        // two lane halves hold interleaved classes, so the merge breaks ties towards the smaller class.
         float best = -INFINITY;
-        uint32_t bestc = 0xffffu;
+        uint32_t bestc = 4 * h;                          // this half's first class (all -inf: class 0, as numpy)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const uint32_t cls = (i & 3) + 8 * (i >> 2) + 4 * h;
-            if (cls < a.L.outDim) {
-                const float v = acc[i];
-                if (a.logits && pidx < a.n) a.logits[pidx * a.L.outDim + cls] = v;
-                if (v > best || (v == best && cls < bestc)) { best = v; bestc = cls; }    // np.argmax: first maximum
-            }
+            const float v = cls < a.L.outDim ? acc[i] : -INFINITY;
+            const bool take = v > best;
+            best = take ? v : best;
+            bestc = take ? cls : bestc;
         }
         const float ob = __shfl_xor(best, 32);
         const uint32_t oc = __shfl_xor(bestc, 32);
         if (ob > best || (ob == best && oc < bestc)) { best = ob; bestc = oc; }
-        if (a.argmax && h == 0 && pidx < a.n) a.argmax[pidx] = (int16_t)bestc;
+        // stored at the top of the next batch: issued here, the store would still be in flight at the
+        // chunk barrier below, whose vmcnt(0) (for the DMA) would then wait out its whole HBM round trip
+        pendIdx = (a.argmax && h == 0 && pidx < a.n) ? pidx : -1;
+        pendVal = (int16_t)bestc;
     }
+    next_chunk();
+    nextFrag = a.L.fragOff[0] + CH0;
+    }   // batch
+    if (pendIdx >= 0) a.argmax[pendIdx] = pendVal;
 }
 
 template <int HID>
 static int launch_inr_kt0(const InrArgs& a, hipStream_t s) {
     const int64_t groups = (a.n + kInrWaves * 32 - 1) / (kInrWaves * 32);
-    const dim3 grid((uint32_t)groups), block(kInrWaves * 64);
     const bool siren = a.kind == MRIRT_INR_SIREN || a.kind == 3u;
-    if (a.L.kt0 == 1) {
-        if (siren) hipLaunchKernelGGL((inr_forward_kernel<HID, 1, true>), grid, block, 0, s, a);
-        else       hipLaunchKernelGGL((inr_forward_kernel<HID, 1, false>), grid, block, 0, s, a);
-    } else {
-        if (siren) hipLaunchKernelGGL((inr_forward_kernel<HID, 4, true>), grid, block, 0, s, a);
-        else       hipLaunchKernelGGL((inr_forward_kernel<HID, 4, false>), grid, block, 0, s, a);
+    void (*kern)(const InrArgs) = a.L.kt0 == 1
+        ? (siren ? inr_forward_kernel<HID, 1, true> : inr_forward_kernel<HID, 1, false>)
+        : (siren ? inr_forward_kernel<HID, 4, true> : inr_forward_kernel<HID, 4, false>);
+    // persistent workgroups: as many as are resident at once (the 4 x 256 nets: one per CU, 150 KB of LDS)
+    static int resident[2][2] = { { 0, 0 }, { 0, 0 } };
+    int& res = resident[a.L.kt0 == 1 ? 0 : 1][siren ? 1 : 0];
+    if (res == 0) {
+        int dev = 0, cus = 0, perCu = 0;
+        MRIRT_HIP(hipGetDevice(&dev));
+        MRIRT_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        MRIRT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, kern, kInrWaves * 64, 0));
+        res = (cus > 0 ? cus : 256) * (perCu > 0 ? perCu : 1);
     }
+    const dim3 grid((uint32_t)(groups < res ? groups : res)), block(kInrWaves * 64);
+    hipLaunchKernelGGL(kern, grid, block, 0, s, a);
     MRIRT_HIP(hipGetLastError());
     return MRIRT_OK;
 }
