@@ -227,7 +227,7 @@ __global__ __launch_bounds__(512) void inr_forward_kernel(const InrArgs a) {
         const int64_t p = pidx < a.n ? pidx : a.n - 1;   // clamp: compute something, store nothing
         if (a.kind < 2) {
             // lane half 0 stages its point's raw inputs (3 coords + <= 8 modalities + a zero) in LDS ...
-            float* raw = ldsRaw + (waveS * 32 + r) * kRawStride;
+            float* raw = ldsRaw + waveS * 32 * kRawStride + r;       // [input][point]: lanes of a half hit 32 banks
             if (h == 0) {
                 float c[3], m[kMaxMods];
                 const uint32_t M = a.M;
@@ -244,10 +244,11 @@ __global__ __launch_bounds__(512) void inr_forward_kernel(const InrArgs a) {
 #pragma unroll
                     for (uint32_t g = 0; g < kMaxMods; ++g) m[g] = M ? a.feats[p * (int64_t)M + (g < M ? g : M - 1)] : 0.0f;
                 }
-                float4* rq = reinterpret_cast<float4*>(raw);
-                rq[0] = make_float4(c[0], c[1], c[2], m[0]);
-                rq[1] = make_float4(m[1], m[2], m[3], m[4]);
-                rq[2] = make_float4(m[5], m[6], m[7], 0.0f);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) raw[32 * k] = c[k];
+#pragma unroll
+                for (int k = 0; k < kMaxMods; ++k) raw[32 * (3 + k)] = m[k];
+                raw[32 * (kRawStride - 1)] = 0.0f;
             }
             // ... and both halves build their features from the table (same wave: LDS ops are in order)
             // (eight descriptors, then eight raw values, then the arithmetic: two LDS latencies per k step
@@ -262,7 +263,7 @@ __global__ __launch_bounds__(512) void inr_forward_kernel(const InrArgs a) {
                     for (int j = 0; j < 8; ++j) d[j] = ldsTab[32 * t + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3)];
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) x[j] = raw[__builtin_bit_cast(uint32_t, d[j].z)];
+                    for (int j = 0; j < 8; ++j) x[j] = raw[32 * __builtin_bit_cast(uint32_t, d[j].z)];
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
