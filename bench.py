@@ -64,14 +64,14 @@ def parse():
 
 
 def measured_traffic(key):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json), or
-    None when this configuration has not been profiled."""
+    """(HBM bytes per launch, on-chip utilisation figures) from the committed rocprofv3 PMC passes
+    (profiles/traffic.json), or (None, None) when this configuration has not been profiled."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
             entry = json.load(fh).get(key)
-        return int(entry["hbm_bytes_per_launch"]) if entry else None
+        return (int(entry["hbm_bytes_per_launch"]), entry.get("on_chip")) if entry else (None, None)
     except (OSError, ValueError, KeyError):
-        return None
+        return None, None
 
 
 def cpu_baseline(params, vol, ext, rows, n_image):
@@ -207,6 +207,10 @@ def main():
         px = local.numel() // 4
         alg_bytes = my_live * BYTES_PER_SAMPLE + my_shaded * BYTES_PER_SHADED + px * BYTES_PER_PIXEL
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        profiled = world == 1 and a.variant == 0 and a.alpha == 16.0
+        traffic, on_chip = measured_traffic(
+            f"{'C3' if not a.no_shade else 'K1'}:{n}:{image}:{a.march_steps}:{a.layout}:{a.math}:"
+            f"{'shade' if not a.no_shade else 'plain'}") if profiled else (None, None)
         out = {
             "metric": "live Msamples/s, 512^3 fp32 volume @ 1024^2 x 512 steps (gradient shading + ERT)",
             "value": round(value, 1), "unit": "Msamples/s",
@@ -225,9 +229,10 @@ def main():
                        "kernel_variant": a.variant},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": measured_traffic(
-                             f"{'C3' if not a.no_shade else 'K1'}:{n}:{image}:{a.march_steps}:{a.layout}:{a.math}:"
-                             f"{'shade' if not a.no_shade else 'plain'}") if world == 1 and a.variant == 0 and a.alpha == 16.0 else None,
+                         "traffic": traffic,
+                         # what actually binds the kernel (PMC passes, profiles/traffic.json): its gathers are
+                         # served by L1/L2, so the HBM fraction above exceeds 1 and says little by itself
+                         "on_chip": on_chip,
                          "kernel": "brats_march_pipe_kernel" if not a.variant & 4 else "brats_march_kernel", "kernel_ms": round(kernel_ms, 4),
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "compulsory_bytes_per_launch": grid.nbytes + px * BYTES_PER_PIXEL,   # volume once + framebuffer
