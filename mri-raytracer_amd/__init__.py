@@ -12,7 +12,7 @@ the task-mandated name ``mri-raytracer_amd``.  Layout:
   tiles.py    image-tile sharding + RCCL framebuffer gather (one process per GPU)
   synth.py    deterministic synthetic scenes for tests and bench
 """
-from . import _lib, camera, inr, nifti, params, render, shim, synth, tiles, viewer, volume  # noqa: F401
+from . import _lib, camera, inr, nifti, params, render, shim, synth, tiles, torch_ops, viewer, volume  # noqa: F401
 from .camera import OrbitalCamera  # noqa: F401
 from .inr import apply_mlp, build_input, inr_forward, model_load, predict_volume, render_brats_inr  # noqa: F401
 from .shim import Device, KernelShim  # noqa: F401

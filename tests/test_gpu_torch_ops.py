@@ -1,0 +1,71 @@
+"""torch.ops.mrirt.* (mrirt/torch_ops.py): the registered operators launch the same C-ABI entry points
+as the Python API, so their frames must be bit-identical to it — and through it to the oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_render_brats_op_equals_api_and_oracle():
+    import torch
+    import mrirt
+    from mrirt import synth, torch_ops
+    from oracle import oracle_c
+    n, image = 40, 96
+    vol = synth.synth_volume(n)
+    lab = synth.synth_labels(n)
+    p = synth.brats_scene(n, image, 64, channels=1, intensity_alpha=8.0)
+    p["showSeg"] = 1
+    ref = oracle_c.brats_main(p, [vol], lab, None, dict(synth.SHADE_EXT))
+    for layout in ("linear", "vg"):
+        ext = dict(synth.SHADE_EXT, layout=layout, labelLayout="linear")
+        g = mrirt.upload_grid(vol, (n, n, n), layout)
+        labels = torch.from_numpy(lab.astype(np.int32)).cuda()
+        api = mrirt.render_brats(p, [g], labels=labels, ext=ext)
+        op = torch.ops.mrirt.render_brats(torch_ops.pack_brats_params(p), torch_ops.pack_render_ext(ext),
+                                          g.data, None, None, None, labels, None)
+        assert torch.equal(op, api)
+        assert np.array_equal(op.cpu().numpy(), ref)
+    # the size checks the C ABI cannot make
+    with pytest.raises(ValueError):
+        torch.ops.mrirt.render_brats(torch_ops.pack_brats_params(p), torch_ops.pack_render_ext(ext),
+                                     g.data[:100], None, None, None, labels, None)
+    with pytest.raises(TypeError):
+        torch.ops.mrirt.render_brats(torch_ops.pack_brats_params(p)[:-1], torch_ops.pack_render_ext(ext),
+                                     g.data, None, None, None, labels, None)
+
+
+def test_render_volume_and_sdf_ops():
+    import torch
+    import mrirt
+    from mrirt import synth, torch_ops
+    p = synth.volume_scene(32, 80, 48)
+    vol_u8 = synth.synth_u8_volume(32)
+    t = torch.from_numpy(np.ascontiguousarray(vol_u8.reshape(-1))).cuda()
+    api = mrirt.render_volume_u8(p, t, mode="u8")
+    op = torch.ops.mrirt.render_volume(torch_ops.pack_volume_params(p), torch_ops.pack_render_ext(None), t, 1)
+    assert torch.equal(op, api)
+    assert float(api[..., 0].max()) > 0.05
+    # the reference's own upload format: one uint32 per voxel (app.py:149-153)
+    tp = torch.from_numpy(mrirt.volume.pack_u8_as_u32x4(vol_u8).astype(np.int64).astype(np.int32)).cuda().reshape(-1)
+    assert torch.equal(torch.ops.mrirt.render_volume(torch_ops.pack_volume_params(p), torch_ops.pack_render_ext(None), tp, 0), api)
+    sp, eye, U, V, W = synth.sdf_scene()
+    api3 = mrirt.render_sdf(sp, eye, U, V, W, 72, 40)
+    op3 = torch.ops.mrirt.render_sdf(torch_ops.pack_sdf_params(sp, eye, U, V, W), 72, 40, api3)
+    assert torch.equal(op3, api3)
+
+
+def test_inr_forward_op_equals_api():
+    import torch
+    from mrirt import inr
+    rng = np.random.default_rng(5)
+    dims = [7, 64, 64, 4]
+    params = [{"W": (rng.standard_normal((dims[i], dims[i + 1])) * 0.3).astype(np.float32),
+               "b": (rng.standard_normal(dims[i + 1]) * 0.1).astype(np.float32)} for i in range(3)]
+    net = inr.pack_mlp(params, inr.KIND_SIREN, 0, 4, w0=30.0)
+    n = 1000
+    coords = (torch.rand((n, 3), device="cuda") * 2 - 1).contiguous()
+    feats = torch.rand((n, 4), device="cuda").contiguous()
+    api, _ = inr._forward(net, coords, feats, n, True, False)
+    op = torch.ops.mrirt.inr_forward(net.weights, net.biases, inr.KIND_SIREN, 3, 7, 4, 64, 0, 4, 30.0, coords, feats, n)
+    assert torch.equal(op, api)

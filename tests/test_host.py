@@ -180,3 +180,29 @@ def test_model_load_both_layouts(golden_dir, tmp_path):
     assert np.array_equal(got2[0]["W"], params[0]["W"])
     with pytest.raises(FileNotFoundError):
         mrirt.inr.model_load(tmp_path / "missing.npz")
+
+
+def test_torch_ops_are_registered_with_shape_functions():
+    """torch.ops.mrirt.*: present, the parameter blobs are the C structs byte for byte, and the shape
+    functions answer on meta tensors (no GPU, no compute)."""
+    import ctypes as C
+    import torch
+    from mrirt import _lib, torch_ops
+    for name in ("render_brats", "render_volume", "render_sdf", "inr_forward"):
+        assert hasattr(torch.ops.mrirt, name)
+    p = synth.brats_scene(32, 64, 32, channels=1)
+    blob, ext = torch_ops.pack_brats_params(p), torch_ops.pack_render_ext({"layout": "vg", "outFormat": "rgba16f"})
+    assert blob.numel() == C.sizeof(_lib.BratsParams) == 368 and ext.numel() == C.sizeof(_lib.RenderExt)
+    back = _lib.BratsParams.from_buffer_copy(blob.numpy().tobytes())
+    assert tuple(back.imageSize) == (64, 64) and tuple(back.dims) == (32, 32, 32)
+    v = torch.empty(4 * 16 ** 3 * 8, device="meta")
+    o = torch.ops.mrirt.render_brats(blob, ext, v, None, None, None, None, None)
+    assert o.shape == (64, 64, 4) and o.dtype == torch.float16 and o.device.type == "meta"
+    tiled = torch_ops.pack_render_ext({"tileSize": 16, "tileRank": 1, "tileWorld": 3})
+    o = torch.ops.mrirt.render_brats(blob, tiled, torch.empty(32 ** 3, device="meta"), None, None, None, None, None)
+    assert o.shape == (mrirt.tiles.local_tile_count(64, 64, 16, 1, 3), 16, 16, 4)
+    o = torch.ops.mrirt.inr_forward(torch.empty(1, dtype=torch.uint8, device="meta"), torch.empty(1, device="meta"),
+                                    1, 3, 7, 4, 64, 0, 4, 30.0, None, None, 10)
+    assert o.shape == (10, 4)
+    with pytest.raises(TypeError):
+        torch.ops.mrirt.render_brats(blob[:-4], ext, v, None, None, None, None, None)
