@@ -67,7 +67,7 @@ typedef enum MrirtLayout {
     MRIRT_LAYOUT_BRICK = 1,
     /* fp32 intensity grids only: one float4 per voxel, 2x2x2-voxel bricks (8 x 16 B = one 128-B
      * line).  VG   = (v, dv/dx, dv/dy, dv/dz) with the lattice central differences
-     *                v[clamp(c+e)] - v[clamp(c-e)] precomputed at load time (mrirt_build_vg_grid):
+     *                v[clamp(c+e)] - v[clamp(c-e)] precomputed at load time (mrirt_build_vec4_grid):
      *                a gradient-shaded sample is 8 dwordx4 gathers instead of 32 dword gathers,
      *                bit-identical arithmetic.
      *        QUAD = (v[x,y], v[x+1,y], v[x,y+1], v[x+1,y+1]) (indices clamped): an unshaded
@@ -212,7 +212,12 @@ int mrirt_detile(const void* gathered, void* frame, uint32_t width, uint32_t hei
 /* ------------------------------------------------------------------------------------ */
 /* INR forward (inr/inr/model.py:11-50,119-141; notebooks/neumors_inr.ipynb:1165-1178)   */
 /* ------------------------------------------------------------------------------------ */
-typedef enum MrirtInrKind { MRIRT_INR_FOURIER_RELU = 0, MRIRT_INR_SIREN = 1 } MrirtInrKind;
+typedef enum MrirtInrKind {
+    MRIRT_INR_FOURIER_RELU = 0,   /* inputs built on the device: coords, Fourier features, modalities; ReLU */
+    MRIRT_INR_SIREN = 1,          /* inputs (coords, modalities); sin activations, first layer scaled by w0 */
+    MRIRT_INR_RAW_RELU = 2,       /* feats IS the [n][inDim] input matrix (apply_mlp); ReLU                 */
+    MRIRT_INR_RAW_SIREN = 3       /* the same with the SIREN activations                                    */
+} MrirtInrKind;
 
 typedef struct MrirtInrDesc {
     uint32_t kind;           /* MrirtInrKind                                                    */
@@ -221,15 +226,18 @@ typedef struct MrirtInrDesc {
     uint32_t outDim;         /* classes (<= 16)                                                 */
     uint32_t hidden;         /* hidden width (multiple of 32, <= 256)                           */
     uint32_t fourierFreqs;   /* K (Fourier kind)                                                */
-    uint32_t numMods;        /* M                                                               */
+    uint32_t numMods;        /* M (<= 8 for kinds 0 and 1: the kernel stages 3 + 8 raw inputs per point) */
     float    w0;             /* SIREN first-layer frequency (30)                                */
     const void* weights;     /* device: packed bf16 weights, see mrirt_inr_pack_bytes           */
     const float* biases;     /* device: fp32 biases, layers concatenated, each padded to its padded out width */
 } MrirtInrDesc;
 
-/* bytes of the packed bf16 weight image for a network shape */
+/* bytes to allocate for the packed bf16 weight image of a network shape (0: unsupported shape).  Includes
+ * 64 KiB of slack after the image proper: the kernel's last weight-chunk prefetch reads (and ignores) it. */
 int64_t mrirt_inr_pack_bytes(const MrirtInrDesc* desc);
-/* pack fp32 row-major [in,out] weights (device, layers concatenated unpadded) into the MFMA image */
+/* pack fp32 row-major [in,out] weights (device, layers concatenated unpadded) into the MFMA image.  The
+ * image depends on desc->kind and desc->w0 (the SIREN's w0 / 2 pi and 1 / 2 pi are folded into it): pack
+ * and forward with the same descriptor. */
 int mrirt_inr_pack_weights(const MrirtInrDesc* desc, const float* w_f32, void* packed, void* stream);
 /* logits[n][outDim] (fp32) and/or argmax[n] (int16) for n points.
  * coords[n][3] in [-1,1]; feats[n][numMods].  Either output may be NULL.                 */
