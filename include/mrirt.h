@@ -160,6 +160,9 @@ int mrirt_unbrick_grid(const void* bricked, void* linear, const uint32_t dims[3]
 int64_t mrirt_vec4_elems(const uint32_t dims[3]);
 /* linear fp32 (x fastest) -> VG or QUAD float4 grid (layout = MRIRT_LAYOUT_VG / _QUAD). */
 int mrirt_build_vec4_grid(const float* linear, void* vec4_grid, const uint32_t dims[3], uint32_t layout, void* stream);
+/* BC4 / RGTC1-unorm slices (8-byte blocks, [depth][ceil(h/4)][ceil(w/4)], device, 8-byte aligned) -> u8 voxels
+ * [depth][height][width]: the decode scripts/volumeRendering/app.py:200-250 does on the host. */
+int mrirt_bc4_decode(const void* blocks, uint32_t width, uint32_t height, uint32_t depth, uint8_t* out_u8, void* stream);
 
 /* ------------------------------------------------------------------------------------ */
 /* K2  volume_cs                                                                         */

@@ -80,6 +80,44 @@ __global__ __launch_bounds__(256) void detile_kernel(const void* __restrict__ ga
     else reinterpret_cast<float4*>(frame)[dst] = reinterpret_cast<const float4*>(gathered)[src];
 }
 
+// BC4 / RGTC1-unorm slices -> u8 voxels [D][H][W] (scripts/volumeRendering/app.py:200-250).  One thread per
+// 4x4 block: 8 bytes in (two endpoints, 16 three-bit codes), up to 16 bytes out.  r0 > r1: six
+// interpolants ((7-i) r0 + i r1 + 3) / 7; else four ((5-i) r0 + i r1 + 2) / 5, then 0 and 255.
+__global__ __launch_bounds__(256) void bc4_decode_kernel(const uint2* __restrict__ blocks, uint8_t* __restrict__ out,
+                                                         uint32_t width, uint32_t height, uint32_t depth,
+                                                         uint32_t bw, uint32_t bh) {
+    const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= (uint64_t)bw * bh * depth) return;
+    const uint32_t bx = (uint32_t)(b % bw), by = (uint32_t)((b / bw) % bh), z = (uint32_t)(b / ((uint64_t)bw * bh));
+    const uint2 q = blocks[b];
+    const int r0 = (int)(q.x & 0xffu), r1 = (int)((q.x >> 8) & 0xffu);
+    const uint64_t bits = (uint64_t)(q.x >> 16) | ((uint64_t)q.y << 16);          // bytes 2..7, little endian
+    int pal[8];
+    pal[0] = r0; pal[1] = r1;
+    const bool six = r0 > r1;
+#pragma unroll
+    for (int i = 1; i <= 6; ++i) {
+        const int a6 = ((7 - i) * r0 + i * r1 + 3) / 7;
+        const int a4 = i <= 4 ? ((5 - i) * r0 + i * r1 + 2) / 5 : (i == 5 ? 0 : 255);
+        pal[i + 1] = six ? a6 : a4;
+    }
+#pragma unroll
+    for (int ty = 0; ty < 4; ++ty) {
+        const uint32_t y = by * 4 + ty;
+        if (y >= height) break;
+#pragma unroll
+        for (int tx = 0; tx < 4; ++tx) {
+            const uint32_t x = bx * 4 + tx;
+            if (x >= width) break;
+            const uint32_t code = (uint32_t)(bits >> (3 * (ty * 4 + tx))) & 7u;
+            int v = pal[0];
+#pragma unroll
+            for (int k = 1; k < 8; ++k) v = code == (uint32_t)k ? pal[k] : v;      // no dynamic register indexing
+            out[((uint64_t)z * height + y) * width + x] = (uint8_t)v;
+        }
+    }
+}
+
 static int brick_common(const void* src, void* dst, const uint32_t dims[3], uint32_t elem_bytes, bool toBrick, void* stream) {
     if (!src || !dst || !dims) return MRIRT_ERR_NULL;
     for (int k = 0; k < 3; ++k) if (dims[k] < 1) return MRIRT_ERR_DIMS;
@@ -137,6 +175,20 @@ extern "C" int mrirt_build_vec4_grid(const float* linear, void* vec4_grid, const
         hipLaunchKernelGGL((vec4_build_kernel<true>), grid, block, 0, s, linear, (float4*)vec4_grid, dims[0], dims[1], dims[2], nbx, nby, total);
     else
         hipLaunchKernelGGL((vec4_build_kernel<false>), grid, block, 0, s, linear, (float4*)vec4_grid, dims[0], dims[1], dims[2], nbx, nby, total);
+    MRIRT_HIP(hipGetLastError());
+    return MRIRT_OK;
+}
+
+extern "C" int mrirt_bc4_decode(const void* blocks, uint32_t width, uint32_t height, uint32_t depth,
+                                uint8_t* out_u8, void* stream) {
+    if (!blocks || !out_u8) return MRIRT_ERR_NULL;
+    if (width == 0 || height == 0 || depth == 0) return MRIRT_ERR_DIMS;
+    const uint32_t bw = (width + 3) / 4, bh = (height + 3) / 4;
+    const uint64_t nblk = (uint64_t)bw * bh * depth;
+    if (nblk >= (1ull << 31) * 256) return MRIRT_ERR_DIMS;
+    if ((reinterpret_cast<uintptr_t>(blocks) & 7u) != 0) return MRIRT_ERR_ARG;      // 8-byte blocks, read as uint2
+    hipLaunchKernelGGL(bc4_decode_kernel, dim3((uint32_t)((nblk + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), static_cast<const uint2*>(blocks), out_u8, width, height, depth, bw, bh);
     MRIRT_HIP(hipGetLastError());
     return MRIRT_OK;
 }

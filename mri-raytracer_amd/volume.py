@@ -102,6 +102,30 @@ def bc4_decode(bc: bytes, width: int, height: int, depth: int) -> np.ndarray:
     return np.ascontiguousarray(img[:, :height, :width]).reshape(-1)
 
 
+def bc4_decode_device(bc, width: int, height: int, depth: int, stream=None):
+    """The same decode on the GPU (csrc/grid_ops.hip): ``bc`` is the block stream as bytes, a NumPy uint8
+    array or a device uint8 tensor; returns the flattened (D*H*W,) device uint8 tensor, ready to be bound as
+    ``gVolumeU8`` with ``mode='u8'``."""
+    import ctypes as C
+    import torch
+    from . import _lib
+    if not torch.cuda.is_available():
+        raise RuntimeError("bc4_decode_device needs an MI355X; volume.bc4_decode is the host decode")
+    bw, bh = (width + 3) // 4, (height + 3) // 4
+    want = depth * bw * bh * 8
+    if isinstance(bc, (bytes, bytearray, memoryview)):
+        bc = np.frombuffer(bytes(bc), dtype=np.uint8)
+    t = torch.as_tensor(bc)
+    if t.dtype != torch.uint8 or t.numel() != want:
+        raise RuntimeError(f"BC4 data size mismatch: {t.numel()} vs {want}")
+    t = t.reshape(-1).cuda().contiguous()
+    out = torch.empty(depth * height * width, dtype=torch.uint8, device=t.device)
+    s = C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
+    _lib.check(_lib.lib().mrirt_bc4_decode(C.c_void_p(t.data_ptr()), width, height, depth, C.c_void_p(out.data_ptr()), s),
+               "mrirt_bc4_decode")
+    return out
+
+
 def zscore_nonzero(arr: np.ndarray) -> np.ndarray:
     """Per-modality z-score over non-zero voxels, sigma + 1e-6 (brats_viewer.py:281-287)."""
     a = np.asarray(arr, dtype=np.float32)

@@ -312,3 +312,25 @@ def test_full_size_properties(env):
     c2 = mrirt.render_brats(p2, [gb], ext=ext).cpu().numpy()
     miss = img[..., 0] == 0.0
     assert np.all(c2[..., 0][miss] == 0.25)
+
+
+def test_bc4_decode_on_device_matches_host_and_oracle():
+    """mrirt_bc4_decode == volume.bc4_decode == the oracle's decode, incl. ragged (non-multiple-of-4) sizes
+    and both palette modes (r0 > r1 and r0 <= r1)."""
+    import torch
+    from mrirt import volume
+    from oracle import oracle_np as onp
+    rng = np.random.default_rng(11)
+    for (w, h, d) in ((16, 12, 5), (13, 7, 3), (4, 4, 1), (1, 1, 2), (37, 41, 9)):
+        bw, bh = (w + 3) // 4, (h + 3) // 4
+        blk = rng.integers(0, 256, size=(d, bh, bw, 8), dtype=np.uint8)
+        blk[0, 0, 0, :2] = (200, 10)          # six-interpolant mode
+        blk[-1, -1, -1, :2] = (10, 200)       # four-interpolant mode with 0 / 255
+        if bw > 1:
+            blk[0, 0, 1, :2] = (77, 77)       # r0 == r1 -> four-interpolant branch
+        data = blk.tobytes()
+        host = volume.bc4_decode(data, w, h, d)
+        assert np.array_equal(host, onp.bc4_decode(data, w, h, d))
+        dev = volume.bc4_decode_device(data, w, h, d)
+        assert dev.dtype == torch.uint8 and dev.numel() == w * h * d
+        assert np.array_equal(dev.cpu().numpy(), host)
