@@ -206,6 +206,29 @@ int mrirt_render_sdf(const MrirtSdfParams* params, uint32_t width, uint32_t heig
 /* ------------------------------------------------------------------------------------ */
 /* Tile sharding helpers (multi-GPU)                               */
 /* ------------------------------------------------------------------------------------ */
+/* Exact empty-space skipping (build-defined acceleration).  The frame and the
+ * sample counters are bit-identical to mrirt_render_brats_ex: a sample in a skipped macro cell still
+ * counts as a march step, it just fetches and composites nothing, and a macro cell (8^3 voxels) is skipped
+ * only when an upper bound of every enabled modality there cannot lift the transfer function above 0 for
+ * THIS launch's window / weights and no shown label grid has a label there.  Applies to the VG / QUAD
+ * pipelined kernels; any other configuration renders without skipping.                                   */
+typedef struct MrirtSkip {
+    const float* macroUb[4];      /* per modality: mrirt_build_macro_max output, or NULL (modality unused)   */
+    const uint32_t* macroSeg;     /* mrirt_build_macro_labels of gLabels (needed when showSeg)               */
+    const uint32_t* macroPred;    /* ... of gPreds (needed when showPred)                                    */
+    uint32_t* mask;               /* scratch, mrirt_skip_mask_words(dims) uint32: rewritten by every launch  */
+} MrirtSkip;
+int64_t mrirt_macro_cells(const uint32_t dims[3]);
+int64_t mrirt_skip_mask_words(const uint32_t dims[3]);
+/* from the LINEAR (x fastest) fp32 / uint32 grids, before any layout conversion */
+int mrirt_build_macro_max(const float* linear, const uint32_t dims[3], float* macro_ub, void* stream);
+int mrirt_build_macro_labels(const uint32_t* labels_linear, const uint32_t dims[3], uint32_t* macro_any, void* stream);
+int mrirt_render_brats_skip(const MrirtBratsParams* params, const MrirtRenderExt* ext,
+                            const void* const vol[4], const void* labels, const void* preds,
+                            const MrirtSkip* skip, void* out_rgba, int64_t pitch_px,
+                            uint64_t* stats_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------ */
 /* number of tiles rank `rank` of `world` renders for a W x H image */
 int64_t mrirt_tiles_for_rank(uint32_t width, uint32_t height, uint32_t tileSize, uint32_t rank, uint32_t world);
 /* scatter gathered compact tile buffers [world][max_local][ts][ts][4] back into a pitch-linear frame */

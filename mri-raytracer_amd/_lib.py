@@ -22,7 +22,8 @@ HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-s
 ABI_SYMBOLS = [
     "mrirt_render_brats", "mrirt_render_brats_ex", "mrirt_brats_sample_counts", "mrirt_brats_emit_samples",
     "mrirt_render_brats_stream", "mrirt_brick_elems", "mrirt_brick_grid",
-    "mrirt_unbrick_grid", "mrirt_vec4_elems", "mrirt_build_vec4_grid", "mrirt_bc4_decode", "mrirt_render_volume", "mrirt_render_sdf", "mrirt_tiles_for_rank",
+    "mrirt_unbrick_grid", "mrirt_vec4_elems", "mrirt_build_vec4_grid", "mrirt_bc4_decode", "mrirt_macro_cells", "mrirt_skip_mask_words",
+    "mrirt_build_macro_max", "mrirt_build_macro_labels", "mrirt_render_brats_skip", "mrirt_render_volume", "mrirt_render_sdf", "mrirt_tiles_for_rank",
     "mrirt_detile", "mrirt_inr_pack_bytes", "mrirt_inr_pack_weights", "mrirt_inr_forward",
     "mrirt_inr_predict_volume", "mrirt_abi_version", "mrirt_status_string", "mrirt_last_hip_error",
     "mrirt_sizeof",
@@ -93,6 +94,11 @@ class InrDesc(C.Structure):
     ]
 
 
+class Skip(C.Structure):
+    """MrirtSkip: macro-cell summaries + mask scratch for exact empty-space skipping."""
+    _fields_ = [("macroUb", C.c_void_p * 4), ("macroSeg", C.c_void_p), ("macroPred", C.c_void_p), ("mask", C.c_void_p)]
+
+
 class MrirtError(RuntimeError):
     def __init__(self, status: int, where: str):
         l = lib()
@@ -159,6 +165,16 @@ def lib() -> C.CDLL:
     l.mrirt_vec4_elems.argtypes = [C.POINTER(u32)]
     l.mrirt_vec4_elems.restype = i64
     l.mrirt_build_vec4_grid.argtypes = [vp, vp, C.POINTER(u32), u32, vp]
+    l.mrirt_macro_cells.argtypes = [C.POINTER(u32)]
+    l.mrirt_macro_cells.restype = i64
+    l.mrirt_skip_mask_words.argtypes = [C.POINTER(u32)]
+    l.mrirt_skip_mask_words.restype = i64
+    l.mrirt_build_macro_max.argtypes = [vp, C.POINTER(u32), vp, vp]
+    l.mrirt_build_macro_max.restype = i32
+    l.mrirt_build_macro_labels.argtypes = [vp, C.POINTER(u32), vp, vp]
+    l.mrirt_build_macro_labels.restype = i32
+    l.mrirt_render_brats_skip.argtypes = [C.POINTER(BratsParams), C.POINTER(RenderExt), C.POINTER(vp), vp, vp, C.POINTER(Skip), vp, i64, vp, vp]
+    l.mrirt_render_brats_skip.restype = i32
     l.mrirt_bc4_decode.argtypes = [vp, u32, u32, u32, vp, vp]
     l.mrirt_bc4_decode.restype = i32
     l.mrirt_render_volume.argtypes = [C.POINTER(VolumeParams), C.POINTER(RenderExt), vp, u32, vp, i64, vp, vp]

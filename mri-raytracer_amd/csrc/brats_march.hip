@@ -51,6 +51,8 @@ struct K1Args {
     const uint32_t* preds;
     const int16_t* classStream;   // C5: prediction label of sample k of ray p at classStream[rayOffsets[p] + k]
     const int64_t* rayOffsets;
+    const uint32_t* skipMask;     // exact empty-space skipping: bit per 8^3 macro cell, 1 = contributes nothing
+    uint32_t mX, mXY;             // macro cells per row / per slice
     void* out;
     uint64_t* stats;
 };
@@ -343,12 +345,33 @@ __global__ __launch_bounds__(256) void brats_march_kernel(const K1Args a) {
 // ---------------------------------------------------------------------------------------
 // LABELS == false: neither overlay is shown, so the stage carries no label words and pIdx dies after
 // locate() — about ten VGPRs less across the two stages, which is what lets the kernel fit 4 waves/SIMD.
-template <int LAYOUT, bool SHADE, int NCH, bool LABELS>
+// SKIP: exact empty-space skipping.  A sample whose 8^3 macro cell is flagged in a.skipMask (per-launch
+// bit mask: no enabled modality can lift the transfer function above 0 there and no shown label grid has
+// a label there — skip_mask_kernel) still counts as a march step, but fetches and composites nothing:
+// the frame and the counters are the same bits as without skipping.  The flag of the lane's current
+// macro cell is cached; the mask is re-read only when the sample leaves the cell.
+struct SkipCursor { uint32_t cell; bool empty; };
+
+template <int LAYOUT, bool SHADE, int NCH, bool LABELS, bool SKIP>
 struct Stage {
     Cell s;
     Taps<LAYOUT, SHADE> taps[NCH];
     Labels lb;
+    bool empty;
+    __device__ __forceinline__ void classify(const K1Args& a, SkipCursor& k) {
+        if constexpr (SKIP) {
+            const uint32_t cell = (s.ix >> 3) + (s.iy >> 3) * a.mX + (s.iz >> 3) * a.mXY;
+            if (cell != k.cell) {
+                k.cell = cell;
+                k.empty = ((a.skipMask[cell >> 5] >> (cell & 31u)) & 1u) != 0;
+            }
+            empty = k.empty;
+        } else {
+            empty = false;
+        }
+    }
     __device__ __forceinline__ void issue(const K1Args& a) {
+        if (SKIP && empty) return;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) taps[c].template issue<false>(a.vol[a.chan[c]], a.grid, s);   // grid < 4 GiB (launch())
         if constexpr (LABELS) fetch_labels(a, s, lb);
@@ -356,6 +379,7 @@ struct Stage {
     template <bool STRICT, bool GAMMA1>
     __device__ __forceinline__ void consume(const K1Args& a, const float rd[3], RayState& r) const {
         using Mm = M<STRICT>;
+        if (SKIP && empty) { ++r.nLive; return; }
         float v = 0.0f, g[3] = { 0.0f, 0.0f, 0.0f };
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {                      // ascending modality order, as the shader
@@ -377,8 +401,8 @@ struct Stage {
     }
 };
 
-template <bool STRICT, int LAYOUT, bool SHADE, int NCH, bool GAMMA1, bool LABELS>
-__global__ __launch_bounds__(256, LABELS ? 3 : 4) void brats_march_pipe_kernel(const K1Args a) {
+template <bool STRICT, int LAYOUT, bool SHADE, int NCH, bool GAMMA1, bool LABELS, bool SKIP>
+__global__ __launch_bounds__(256, (LABELS || SKIP) ? 3 : 4) void brats_march_pipe_kernel(const K1Args a) {
     uint32_t px, py;
     int64_t oidx;
     const int kind = map_pixel(a.map, px, py, oidx);
@@ -387,19 +411,23 @@ __global__ __launch_bounds__(256, LABELS ? 3 : 4) void brats_march_pipe_kernel(c
         float ro[3], rd[3], t0, t1;
         if (setup_ray(a, px, py, ro, rd, t0, t1) && t0 < t1 && 1.0f > a.ert) {   // the while-condition at entry
             float t = t0;
-            Stage<LAYOUT, SHADE, NCH, LABELS> A, B;
+            Stage<LAYOUT, SHADE, NCH, LABELS, SKIP> A, B;
+            SkipCursor cur = { 0xffffffffu, false };
             locate<STRICT>(a, ro, rd, t, A.s);
+            A.classify(a, cur);
             A.issue(a);
             while (true) {
                 // invariant: stage A holds the sample at t, and (t < t1 && T > ert) holds
                 float tn = t + a.stepSize;
                 locate<STRICT>(a, ro, rd, tn, B.s);
+                B.classify(a, cur);
                 B.issue(a);                                           // speculative next step
                 A.template consume<STRICT, GAMMA1>(a, rd, r);
                 t = tn;
                 if (!(t < t1 && r.T > a.ert)) break;
                 tn = t + a.stepSize;
                 locate<STRICT>(a, ro, rd, tn, A.s);
+                A.classify(a, cur);
                 A.issue(a);
                 B.template consume<STRICT, GAMMA1>(a, rd, r);
                 t = tn;
@@ -416,12 +444,19 @@ static int launch_pipe(const K1Args& a, hipStream_t s) {
     // the fp64 pow only matters for STRICT (FAST's is two instructions): specialise gamma == 1 there
     // ... and drop the label state when no overlay is shown (STRICT only: FAST already fits)
     const bool overlays = a.showSeg != 0 || a.showPred != 0;
-    if (STRICT && a.gamma == 1.0f && !overlays)
-        hipLaunchKernelGGL((brats_march_pipe_kernel<STRICT, LAYOUT, SHADE, NCH, STRICT, !STRICT>), grid, block, 0, s, a);
-    else if (STRICT && a.gamma == 1.0f)
-        hipLaunchKernelGGL((brats_march_pipe_kernel<STRICT, LAYOUT, SHADE, NCH, STRICT, true>), grid, block, 0, s, a);
-    else
-        hipLaunchKernelGGL((brats_march_pipe_kernel<STRICT, LAYOUT, SHADE, NCH, false, true>), grid, block, 0, s, a);
+    // SKIP exists for the gamma == 1 STRICT kernels and for FAST; any other launch ignores the mask (still exact)
+    const bool skip = a.skipMask != nullptr;
+    if (STRICT && a.gamma == 1.0f && !overlays) {
+        if (skip) hipLaunchKernelGGL((brats_march_pipe_kernel<STRICT, LAYOUT, SHADE, NCH, STRICT, !STRICT, true>), grid, block, 0, s, a);
+        else      hipLaunchKernelGGL((brats_march_pipe_kernel<STRICT, LAYOUT, SHADE, NCH, STRICT, !STRICT, false>), grid, block, 0, s, a);
+    } else if (STRICT && a.gamma == 1.0f) {
+        if (skip) hipLaunchKernelGGL((brats_march_pipe_kernel<STRICT, LAYOUT, SHADE, NCH, STRICT, true, true>), grid, block, 0, s, a);
+        else      hipLaunchKernelGGL((brats_march_pipe_kernel<STRICT, LAYOUT, SHADE, NCH, STRICT, true, false>), grid, block, 0, s, a);
+    } else if (!STRICT && skip) {
+        hipLaunchKernelGGL((brats_march_pipe_kernel<STRICT, LAYOUT, SHADE, NCH, false, true, !STRICT>), grid, block, 0, s, a);
+    } else {
+        hipLaunchKernelGGL((brats_march_pipe_kernel<STRICT, LAYOUT, SHADE, NCH, false, true, false>), grid, block, 0, s, a);
+    }
     MRIRT_HIP(hipGetLastError());
     return MRIRT_OK;
 }
@@ -573,11 +608,49 @@ static int prepare(const MrirtBratsParams* p, const MrirtRenderExt* ext, const v
     a.labels = static_cast<const uint32_t*>(labels);
     a.preds = static_cast<const uint32_t*>(preds);
     a.classStream = nullptr; a.rayOffsets = nullptr;
+    a.skipMask = nullptr; a.mX = a.mXY = 0;
     a.out = nullptr; a.stats = nullptr;
     cfg.layout = layout; cfg.math = math;
     cfg.shade = ext && ext->shadeMode != 0;
     cfg.pipe = a.nch >= 1 && !(variant & 4u);
     return MRIRT_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Exact empty-space skipping: the per-launch mask.  Bit = 1 when, for every sample whose base cell lies in
+// the macro cell, val <= 0 is certain (the same weighted sum / wSum division / window test as the march,
+// evaluated on per-cell upper bounds of the trilinear fetch: every step is monotone, so bound in -> bound
+// out) and no shown label grid holds a label there.
+// ---------------------------------------------------------------------------------------
+struct SkipArgs {
+    uint32_t cells, nch;
+    const float* ub[4];          // compacted like K1Args::chan
+    float w[4];
+    UDiv wsum;
+    float tfLo;
+    const uint32_t* seg;
+    const uint32_t* pred;
+    uint32_t* mask;
+};
+
+template <bool STRICT>
+__global__ __launch_bounds__(256) void skip_mask_kernel(const SkipArgs k) {
+    using Mm = M<STRICT>;
+    const uint32_t cell = blockIdx.x * blockDim.x + threadIdx.x;
+    bool empty = false;
+    if (cell < k.cells) {
+        float v = 0.0f;
+        for (uint32_t c = 0; c < k.nch; ++c) v = Mm::mad(k.ub[c][cell], k.w[c], v);
+        if (k.wsum.d > 0.0f) v = Mm::divu(v, k.wsum);
+        empty = v <= k.tfLo;                                         // NaN / inf bounds: not empty
+        if (k.seg != nullptr && k.seg[cell] != 0u) empty = false;
+        if (k.pred != nullptr && k.pred[cell] != 0u) empty = false;
+    }
+    const uint64_t bits = __ballot(empty);
+    if ((threadIdx.x & 63u) == 0u && cell < ((k.cells + 63u) & ~63u)) {      // mask holds whole ballots only
+        k.mask[cell >> 5] = (uint32_t)bits;
+        k.mask[(cell >> 5) + 1] = (uint32_t)(bits >> 32);
+    }
 }
 
 }  // namespace mrirt
@@ -600,6 +673,48 @@ extern "C" int mrirt_render_brats_ex(const MrirtBratsParams* p, const MrirtRende
     a.stats = stats_dev;
     if (a.map.numBlocks == 0) return MRIRT_OK;   // a rank that owns no tile
     hipStream_t s = static_cast<hipStream_t>(stream);
+    return cfg.math == MRIRT_MATH_STRICT ? launch_layout<true>(a, cfg.layout, cfg.shade, cfg.pipe, s)
+                                         : launch_layout<false>(a, cfg.layout, cfg.shade, cfg.pipe, s);
+}
+
+extern "C" int mrirt_render_brats_skip(const MrirtBratsParams* p, const MrirtRenderExt* ext,
+                                       const void* const vol[4], const void* labels, const void* preds,
+                                       const MrirtSkip* skip, void* out_rgba, int64_t pitch_px,
+                                       uint64_t* stats_dev, void* stream) {
+    if (!out_rgba) return MRIRT_ERR_NULL;
+    if (!skip) return mrirt_render_brats_ex(p, ext, vol, labels, preds, out_rgba, pitch_px, stats_dev, stream);
+    K1Args a;
+    Prepared cfg;
+    int rc = prepare(p, ext, vol, labels, preds, true, pitch_px, a, cfg);
+    if (rc != MRIRT_OK) return rc;
+    if (p->showPred != 0 && !preds) return MRIRT_ERR_NULL;
+    a.out = out_rgba;
+    a.stats = stats_dev;
+    if (a.map.numBlocks == 0) return MRIRT_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // Skipping is sound only where "upper bound <= window floor" implies "contributes nothing": positive
+    // window width and gamma (pow(0, g) = 0), non-negative weights (monotone sum), a bound for every enabled
+    // modality and a label summary for every shown overlay.  Otherwise: the ordinary launch.
+    bool ok = skip->mask != nullptr && p->ww > 0.0f && p->gamma > 0.0f && a.nch >= 1;
+    for (uint32_t c = 0; c < a.nch && ok; ++c)
+        ok = skip->macroUb[a.chan[c]] != nullptr && a.weight[a.chan[c]] >= 0.0f;
+    if (p->showSeg != 0 && !skip->macroSeg) ok = false;
+    if (p->showPred != 0 && !skip->macroPred) ok = false;
+    if (ok) {
+        SkipArgs k;
+        const uint32_t mx = (p->dims[0] + 7) / 8, my = (p->dims[1] + 7) / 8, mz = (p->dims[2] + 7) / 8;
+        k.cells = mx * my * mz; k.nch = a.nch;
+        for (uint32_t c = 0; c < 4; ++c) { k.ub[c] = c < a.nch ? skip->macroUb[a.chan[c]] : nullptr; k.w[c] = c < a.nch ? a.weight[a.chan[c]] : 0.0f; }
+        k.wsum = a.wsum; k.tfLo = a.tfLo;
+        k.seg = p->showSeg != 0 ? skip->macroSeg : nullptr;
+        k.pred = p->showPred != 0 ? skip->macroPred : nullptr;
+        k.mask = skip->mask;
+        const dim3 grid((k.cells + 255) / 256), block(256);
+        if (cfg.math == MRIRT_MATH_STRICT) hipLaunchKernelGGL(skip_mask_kernel<true>, grid, block, 0, s, k);
+        else                               hipLaunchKernelGGL(skip_mask_kernel<false>, grid, block, 0, s, k);
+        MRIRT_HIP(hipGetLastError());
+        a.skipMask = skip->mask; a.mX = mx; a.mXY = mx * my;
+    }
     return cfg.math == MRIRT_MATH_STRICT ? launch_layout<true>(a, cfg.layout, cfg.shade, cfg.pipe, s)
                                          : launch_layout<false>(a, cfg.layout, cfg.shade, cfg.pipe, s);
 }

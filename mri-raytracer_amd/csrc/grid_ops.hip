@@ -118,6 +118,42 @@ __global__ __launch_bounds__(256) void bc4_decode_kernel(const uint2* __restrict
     }
 }
 
+// Macro-cell summaries for exact empty-space skipping (brats_march.hip): macro cell m covers the voxels
+// [8m, 8m+8] per axis (inclusive, so every trilinear cell whose base index lies in [8m, 8m+7] is inside).
+// ub = max + 2e-6 max|v|: three nested unfused lerps exceed the largest corner by at most ~12 ulp of the
+// largest magnitude; 2e-6 is twice that.  A NaN voxel makes the bound +inf (never skipped).
+__global__ __launch_bounds__(256) void macro_max_kernel(const float* __restrict__ lin, float* __restrict__ ub,
+                                                        uint32_t X, uint32_t Y, uint32_t Z, uint32_t mx, uint32_t my, uint32_t cells) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cells) return;
+    const uint32_t cx = c % mx, cy = (c / mx) % my, cz = c / (mx * my);
+    const uint32_t x1 = min(8 * cx + 8, X - 1), y1 = min(8 * cy + 8, Y - 1), z1 = min(8 * cz + 8, Z - 1);
+    float vmax = -INFINITY, amax = 0.0f;
+    bool nan = false;
+    for (uint32_t z = 8 * cz; z <= z1; ++z)
+        for (uint32_t y = 8 * cy; y <= y1; ++y)
+            for (uint32_t x = 8 * cx; x <= x1; ++x) {
+                const float v = lin[x + (size_t)X * (y + (size_t)Y * z)];
+                nan |= v != v;
+                vmax = fmaxf(vmax, v);
+                amax = fmaxf(amax, fabsf(v));
+            }
+    ub[c] = nan ? INFINITY : vmax + 2e-6f * amax;
+}
+
+__global__ __launch_bounds__(256) void macro_label_kernel(const uint32_t* __restrict__ lin, uint32_t* __restrict__ any,
+                                                          uint32_t X, uint32_t Y, uint32_t Z, uint32_t mx, uint32_t my, uint32_t cells) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cells) return;
+    const uint32_t cx = c % mx, cy = (c / mx) % my, cz = c / (mx * my);
+    const uint32_t x1 = min(8 * cx + 8, X - 1), y1 = min(8 * cy + 8, Y - 1), z1 = min(8 * cz + 8, Z - 1);
+    uint32_t acc = 0;
+    for (uint32_t z = 8 * cz; z <= z1; ++z)
+        for (uint32_t y = 8 * cy; y <= y1; ++y)
+            for (uint32_t x = 8 * cx; x <= x1; ++x) acc |= lin[x + (size_t)X * (y + (size_t)Y * z)];
+    any[c] = acc;
+}
+
 static int brick_common(const void* src, void* dst, const uint32_t dims[3], uint32_t elem_bytes, bool toBrick, void* stream) {
     if (!src || !dst || !dims) return MRIRT_ERR_NULL;
     for (int k = 0; k < 3; ++k) if (dims[k] < 1) return MRIRT_ERR_DIMS;
@@ -177,6 +213,37 @@ extern "C" int mrirt_build_vec4_grid(const float* linear, void* vec4_grid, const
         hipLaunchKernelGGL((vec4_build_kernel<false>), grid, block, 0, s, linear, (float4*)vec4_grid, dims[0], dims[1], dims[2], nbx, nby, total);
     MRIRT_HIP(hipGetLastError());
     return MRIRT_OK;
+}
+
+extern "C" int64_t mrirt_macro_cells(const uint32_t dims[3]) {
+    if (!dims) return 0;
+    return (int64_t)((dims[0] + 7) / 8) * ((dims[1] + 7) / 8) * ((dims[2] + 7) / 8);
+}
+
+extern "C" int64_t mrirt_skip_mask_words(const uint32_t dims[3]) {      // whole wave ballots: 2 words per 64 cells
+    return ((mrirt_macro_cells(dims) + 63) / 64) * 2;
+}
+
+static int macro_common(const void* lin, void* out, const uint32_t dims[3], bool labels, void* stream) {
+    if (!lin || !out || !dims) return MRIRT_ERR_NULL;
+    for (int k = 0; k < 3; ++k) if (dims[k] < 1) return MRIRT_ERR_DIMS;
+    const int64_t cells = mrirt_macro_cells(dims);
+    if (cells >= (1ll << 31)) return MRIRT_ERR_DIMS;
+    const uint32_t mx = (dims[0] + 7) / 8, my = (dims[1] + 7) / 8;
+    const dim3 grid((uint32_t)((cells + 255) / 256)), block(256);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (labels) hipLaunchKernelGGL(macro_label_kernel, grid, block, 0, s, (const uint32_t*)lin, (uint32_t*)out, dims[0], dims[1], dims[2], mx, my, (uint32_t)cells);
+    else        hipLaunchKernelGGL(macro_max_kernel, grid, block, 0, s, (const float*)lin, (float*)out, dims[0], dims[1], dims[2], mx, my, (uint32_t)cells);
+    MRIRT_HIP(hipGetLastError());
+    return MRIRT_OK;
+}
+
+extern "C" int mrirt_build_macro_max(const float* linear, const uint32_t dims[3], float* macro_ub, void* stream) {
+    return macro_common(linear, macro_ub, dims, false, stream);
+}
+
+extern "C" int mrirt_build_macro_labels(const uint32_t* labels_linear, const uint32_t dims[3], uint32_t* macro_any, void* stream) {
+    return macro_common(labels_linear, macro_any, dims, true, stream);
 }
 
 extern "C" int mrirt_bc4_decode(const void* blocks, uint32_t width, uint32_t height, uint32_t depth,

@@ -41,7 +41,9 @@ class Grid:
     ``device.create_buffer`` + ``copy_from_numpy`` (inr/viewer/brats_viewer.py:219-230)."""
     data: torch.Tensor            # 1-D, device
     dims: Tuple[int, int, int]    # (X, Y, Z), x fastest in the linear layout
-    layout: str = "linear"        # "linear" | "brick"
+    layout: str = "linear"        # "linear" | "brick" | "vg" | "quad"
+    macro: Optional[torch.Tensor] = None   # per 8^3 macro cell: fp32 upper bound (intensities) / any-label word
+                                           # (label grids) — what exact empty-space skipping tests (skip=True)
 
     @property
     def nbytes(self) -> int:
@@ -58,11 +60,12 @@ def vec4_elems(dims: Sequence[int]) -> int:
     return int(_lib.lib().mrirt_vec4_elems(d))
 
 
-def upload_grid(linear: ArrayLike, dims: Sequence[int], layout: str = "brick", stream=None) -> Grid:
+def upload_grid(linear: ArrayLike, dims: Sequence[int], layout: str = "brick", stream=None, macro: bool = True) -> Grid:
     """Upload a linear (x-fastest) fp32 / uint32 / uint8 grid and convert it on the device
     (csrc/grid_ops.hip) to ``layout``: "linear" (as is), "brick" (4x4x2 bricks), or for fp32
     intensities "vg" (float4 value + lattice gradient) / "quad" (float4 xy-neighbours).
-    Load-time, once per volume."""
+    Load-time, once per volume.  ``macro`` also builds the 8^3 macro-cell summary that
+    ``render_brats(..., skip=True)`` needs (a few hundred KB)."""
     dev = _require_gpu()
     dims = tuple(int(v) for v in dims)
     t = torch.as_tensor(linear).reshape(-1)
@@ -74,8 +77,9 @@ def upload_grid(linear: ArrayLike, dims: Sequence[int], layout: str = "brick", s
     if t.numel() != dims[0] * dims[1] * dims[2]:
         raise ValueError(f"grid has {t.numel()} voxels, dims {dims} need {dims[0] * dims[1] * dims[2]}")
     t = t.to(dev).contiguous()
+    macro = _build_macro(t, dims, stream) if macro else None
     if layout == "linear":
-        return Grid(t, dims, "linear")
+        return Grid(t, dims, "linear", macro)
     if layout in ("vg", "quad"):
         if t.dtype != torch.float32:
             raise TypeError(f"layout {layout!r} is for fp32 intensity grids, got {t.dtype}")
@@ -84,14 +88,30 @@ def upload_grid(linear: ArrayLike, dims: Sequence[int], layout: str = "brick", s
         code = _lib.LAYOUT_VG if layout == "vg" else _lib.LAYOUT_QUAD
         _lib.check(_lib.lib().mrirt_build_vec4_grid(_ptr(t), _ptr(out), d, code, _stream_ptr(stream)),
                    "mrirt_build_vec4_grid")
-        return Grid(out, dims, layout)
+        return Grid(out, dims, layout, macro)
     if layout != "brick":
         raise ValueError(f"unknown layout {layout!r}")
     out = torch.empty(brick_elems(dims), dtype=t.dtype, device=dev)
     d = (C.c_uint32 * 3)(*dims)
     _lib.check(_lib.lib().mrirt_brick_grid(_ptr(t), _ptr(out), d, t.element_size(), _stream_ptr(stream)),
                "mrirt_brick_grid")
-    return Grid(out, dims, "brick")
+    return Grid(out, dims, "brick", macro)
+
+
+def _build_macro(t: torch.Tensor, dims, stream=None) -> Optional[torch.Tensor]:
+    """Macro-cell summary of a LINEAR device grid (csrc/grid_ops.hip): fp32 -> upper bound of the trilinear
+    fetch per 8^3 cell; int32/uint32 labels -> OR of the labels per cell; other dtypes: none."""
+    d = (C.c_uint32 * 3)(*dims)
+    cells = int(_lib.lib().mrirt_macro_cells(d))
+    if t.dtype == torch.float32:
+        out = torch.empty(cells, dtype=torch.float32, device=t.device)
+        _lib.check(_lib.lib().mrirt_build_macro_max(_ptr(t), d, _ptr(out), _stream_ptr(stream)), "mrirt_build_macro_max")
+        return out
+    if t.dtype in (torch.int32, torch.uint32):
+        out = torch.empty(cells, dtype=torch.int32, device=t.device)
+        _lib.check(_lib.lib().mrirt_build_macro_labels(_ptr(t), d, _ptr(out), _stream_ptr(stream)), "mrirt_build_macro_labels")
+        return out
+    return None
 
 
 def unbrick_grid(g: Grid, stream=None) -> torch.Tensor:
@@ -183,25 +203,64 @@ def _bind_brats(params, intensities, labels, preds, ext, dev, pred_stream: bool 
     return P, E, vols, lab, prd
 
 
+_MASKS: dict = {}
+
+
+def _bind_skip(P, intensities, labels, preds, dev):
+    """MrirtSkip for one call: the macro summaries of the bound Grid objects + a cached mask scratch."""
+    S = _lib.Skip()
+    keep = []
+    for m in range(4):
+        g = intensities[m] if m < len(intensities) else None
+        if P.volEnabled[m] != 0:
+            if not isinstance(g, Grid) or g.macro is None or g.macro.dtype != torch.float32:
+                raise ValueError(f"skip=True: gIntensity{m} must be a Grid made by upload_grid (it carries the macro-cell bounds)")
+            S.macroUb[m] = g.macro.data_ptr()
+            keep.append(g.macro)
+    for name, g, flag in (("macroSeg", labels, P.showSeg), ("macroPred", preds, P.showPred)):
+        if flag != 0:
+            if not isinstance(g, Grid) or g.macro is None or g.macro.dtype != torch.int32:
+                raise ValueError("skip=True: a shown label grid must be a Grid made by upload_grid")
+            setattr(S, name, g.macro.data_ptr())
+            keep.append(g.macro)
+    d = (C.c_uint32 * 3)(*[int(v) for v in P.dims])
+    words = int(_lib.lib().mrirt_skip_mask_words(d))
+    key = (dev.index, words)
+    if key not in _MASKS:
+        _MASKS[key] = torch.empty(words, dtype=torch.int32, device=dev)
+    S.mask = _MASKS[key].data_ptr()
+    return S, keep
+
+
 def render_brats(params: Mapping[str, Any], intensities: Sequence[Optional[Union[ArrayLike, Grid]]],
                  labels: Optional[Union[ArrayLike, Grid]] = None, preds: Optional[Union[ArrayLike, Grid]] = None,
                  out: Optional[torch.Tensor] = None, ext: Optional[Mapping[str, Any]] = None,
-                 stats: bool = False, stream=None):
+                 stats: bool = False, stream=None, skip: bool = False):
     """K1 — drop-in for ``kernel.dispatch`` of ``brats_main`` (inr/viewer/brats_viewer.py:431-442).
 
     ``params`` is the reference's ``gParams`` dict; ``intensities`` are ``gIntensity0..3``,
     ``labels``/``preds`` are ``gLabels``/``gPreds``.  Returns the fp32 (H,W,4) frame (or the
     compact tile buffer when ``ext`` shards tiles).  With ``stats=True`` also returns
     ``{"live_samples", "shaded_samples"}`` counted on the device.
+
+    ``skip=True`` turns on exact empty-space skipping (same bits, same counters; needs the bound grids to be
+    ``Grid`` objects carrying their macro-cell summaries, i.e. made by ``upload_grid``): samples in 8^3 macro
+    cells that cannot contribute under this call's window, weights and overlays fetch nothing.
     """
     dev = _require_gpu()
     P, E, vols, lab, prd = _bind_brats(params, intensities, labels, preds, ext, dev)
     o, pitch = _alloc_out(int(P.imageSize[0]), int(P.imageSize[1]), E, dev, out)
     vp = (C.c_void_p * 4)(*[C.c_void_p(t.data_ptr()) if t is not None else None for t in vols])
     st = torch.zeros(2, dtype=torch.int64, device=dev) if stats else None
-    rc = _lib.lib().mrirt_render_brats_ex(C.byref(P), C.byref(E), vp, _ptr(lab), _ptr(prd), _ptr(o),
-                                          pitch, _ptr(st), _stream_ptr(stream))
-    _lib.check(rc, "mrirt_render_brats_ex")
+    if skip:
+        S, keep = _bind_skip(P, intensities, labels, preds, dev)
+        rc = _lib.lib().mrirt_render_brats_skip(C.byref(P), C.byref(E), vp, _ptr(lab), _ptr(prd), C.byref(S), _ptr(o),
+                                                pitch, _ptr(st), _stream_ptr(stream))
+        _lib.check(rc, "mrirt_render_brats_skip")
+    else:
+        rc = _lib.lib().mrirt_render_brats_ex(C.byref(P), C.byref(E), vp, _ptr(lab), _ptr(prd), _ptr(o),
+                                              pitch, _ptr(st), _stream_ptr(stream))
+        _lib.check(rc, "mrirt_render_brats_ex")
     if stats:
         s = st.cpu()
         return o, {"live_samples": int(s[0]), "shaded_samples": int(s[1])}

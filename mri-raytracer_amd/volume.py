@@ -114,7 +114,7 @@ def bc4_decode_device(bc, width: int, height: int, depth: int, stream=None):
     bw, bh = (width + 3) // 4, (height + 3) // 4
     want = depth * bw * bh * 8
     if isinstance(bc, (bytes, bytearray, memoryview)):
-        bc = np.frombuffer(bytes(bc), dtype=np.uint8)
+        bc = np.frombuffer(bytes(bc), dtype=np.uint8).copy()
     t = torch.as_tensor(bc)
     if t.dtype != torch.uint8 or t.numel() != want:
         raise RuntimeError(f"BC4 data size mismatch: {t.numel()} vs {want}")

@@ -1,0 +1,123 @@
+"""Exact empty-space skipping (mrirt_render_brats_skip): the frame and the counters must be the SAME BITS as
+the plain launch — and as the oracle — on volumes that really have empty space, for every kernel family that
+implements it, and on configurations where it must switch itself off."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def head_in_air(n, seed=3, channels=1):
+    """A blob of texture inside zeros (like a skull-stripped scan), plus a label grid with one label blob
+    INSIDE the tissue and one floating in the air (so labels alone must keep those macro cells alive)."""
+    rng = np.random.default_rng(seed)
+    ax = np.linspace(-1, 1, n, dtype=np.float32)
+    z, y, x = np.meshgrid(ax, ax, ax, indexing="ij")
+    r = np.sqrt(x * x + y * y + z * z)
+    vols = []
+    for c in range(channels):
+        v = np.clip(0.9 - r, 0, None) * (0.8 + 0.2 * np.sin((5 + c) * x) * np.cos(4 * y)) + 0.03 * rng.random((n, n, n), dtype=np.float32)
+        v[r > 0.62 + 0.03 * c] = 0.0
+        vols.append(np.ascontiguousarray(v.astype(np.float32)).reshape(-1))
+    lab = np.zeros((n, n, n), np.uint32)
+    lab[r < 0.2] = 3
+    lab[(np.abs(x - 0.8) < 0.08) & (np.abs(y + 0.75) < 0.08) & (np.abs(z - 0.7) < 0.08)] = 2      # in the air
+    return vols, lab.reshape(-1)
+
+
+def mask_fraction(dims):
+    import ctypes as C
+    import torch
+    from mrirt import _lib, render
+    d = (C.c_uint32 * 3)(*dims)
+    cells = int(_lib.lib().mrirt_macro_cells(d))
+    words = int(_lib.lib().mrirt_skip_mask_words(d))
+    m = render._MASKS[(torch.cuda.current_device(), words)].cpu().numpy().view(np.uint32)
+    bits = np.unpackbits(m.view(np.uint8), bitorder="little")[:cells]
+    return float(bits.mean())
+
+
+@pytest.mark.parametrize("layout,shade,channels", [("vg", True, 1), ("vg", False, 1), ("quad", False, 1), ("quad", False, 3)])
+@pytest.mark.parametrize("math", ["strict", "fast"])
+def test_skip_is_bit_identical(layout, shade, channels, math):
+    import torch
+    import mrirt
+    from mrirt import synth
+    n, image = 72, 160
+    vols, lab = head_in_air(n, channels=channels)
+    p = synth.brats_scene(n, image, 192, channels=channels, intensity_alpha=6.0)
+    p["wl"], p["ww"] = np.float32(0.45), np.float32(0.7)            # window floor 0.1 > the air's 0
+    ext = dict(synth.SHADE_EXT) if shade else {}
+    ext.update(layout=layout, math=math)
+    grids = [mrirt.upload_grid(v, (n, n, n), layout) for v in vols]
+    labels = mrirt.upload_grid(lab, (n, n, n), "linear")
+    for show_seg in (0, 1):
+        p["showSeg"] = np.uint32(show_seg)
+        plain, st0 = mrirt.render_brats(p, grids, labels=labels if show_seg else None, ext=ext, stats=True)
+        fast, st1 = mrirt.render_brats(p, grids, labels=labels if show_seg else None, ext=ext, stats=True, skip=True)
+        assert torch.equal(plain, fast)
+        assert st0 == st1
+        frac = mask_fraction((n, n, n))
+        assert frac > 0.5, f"only {frac:.2f} of the macro cells were skippable: the test volume is not doing its job"
+        if show_seg:        # the label blob in the air must be visible, i.e. its cells were not skipped
+            off = mrirt.render_brats({**p, "showSeg": np.uint32(0)}, grids, ext=ext)
+            assert not torch.equal(off, plain)
+
+
+def test_skip_matches_oracle_and_switches_itself_off():
+    import torch
+    import mrirt
+    from mrirt import synth
+    from oracle import oracle_c
+    n, image = 48, 96
+    vols, lab = head_in_air(n, seed=9)
+    p = synth.brats_scene(n, image, 128, channels=1, intensity_alpha=6.0)
+    p["wl"], p["ww"], p["showSeg"] = np.float32(0.45), np.float32(0.7), np.uint32(1)
+    g = mrirt.upload_grid(vols[0], (n, n, n), "quad")
+    labels = mrirt.upload_grid(lab, (n, n, n), "linear")
+    ref = oracle_c.brats_main(p, [vols[0]], lab, None)
+    got = mrirt.render_brats(p, [g], labels=labels, skip=True)
+    assert np.array_equal(got.cpu().numpy(), ref)
+    # configurations where "bound <= window floor" proves nothing: the launch must ignore the mask
+    for change in ({"gamma": np.float32(0.5)}, {"ww": np.float32(-0.7)}, {"volWeight": (np.float32(-1.0), 0, 0, 0)}):
+        q = {**p, **change}
+        a = mrirt.render_brats(q, [g], labels=labels)
+        b = mrirt.render_brats(q, [g], labels=labels, skip=True)
+        assert torch.equal(a, b), change
+    # layouts without the pipelined kernel simply render as before
+    gl = mrirt.upload_grid(vols[0], (n, n, n), "linear")
+    assert torch.equal(mrirt.render_brats(p, [gl], labels=labels, skip=True), got)
+    # raw arrays cannot be skipped: they carry no macro summary
+    with pytest.raises(ValueError):
+        mrirt.render_brats(p, [vols[0]], labels=labels, skip=True)
+
+
+def test_skip_speeds_up_a_sparse_volume():
+    """Not a benchmark — a guard that skipping actually skips: on a 256^3 blob-in-air the skipping launch
+    must be clearly faster than the plain one."""
+    import torch
+    import mrirt
+    from mrirt import synth
+    n, image = 256, 512
+    vols, _ = head_in_air(n, seed=1)
+    p = synth.brats_scene(n, image, 384, channels=1, intensity_alpha=2.0)
+    p["wl"], p["ww"] = np.float32(0.45), np.float32(0.7)
+    ext = dict(synth.SHADE_EXT, layout="vg")
+    g = mrirt.upload_grid(vols[0], (n, n, n), "vg")
+    out = torch.empty((image, image, 4), device="cuda")
+
+    def timed(skip):
+        for _ in range(3):
+            mrirt.render_brats(p, [g], out=out, ext=ext, skip=skip)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            mrirt.render_brats(p, [g], out=out, ext=ext, skip=skip)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / 10, out.clone()
+    t_plain, f_plain = timed(False)
+    t_skip, f_skip = timed(True)
+    assert torch.equal(f_plain, f_skip)
+    print(f"\n256^3 blob in air, 512^2 x 384 steps, VG shaded strict: plain {t_plain:.3f} ms, skipping {t_skip:.3f} ms")
+    assert t_skip < 0.85 * t_plain
