@@ -167,7 +167,10 @@ class ComputeKernel:
         lays = [vlay] * 4 + [llay] * 2
         bound = [self._buf(b, dims, lay) if on else None for b, on, lay in zip(raw, en, lays)]
         e["layout"], e["labelLayout"] = vlay, llay
-        _r.render_brats(p, bound[:4], bound[4], bound[5], out=tex.tensor, ext=e)
+        # exact empty-space skipping rides on the macro-cell summaries upload_grid attached to the cached grids
+        skip = (self.device.skip_empty and vlay in ("vg", "quad")
+                and all(b is None or (isinstance(b, _r.Grid) and b.macro is not None) for b in bound))
+        _r.render_brats(p, bound[:4], bound[4], bound[5], out=tex.tensor, ext=e, skip=skip)
 
     def _volume(self, tc, vars, ext):
         p, tex = vars["gParams"], vars["gOutput"]
@@ -190,12 +193,15 @@ class ComputeKernel:
 class Device:
     """Stands where ``spy.Device(...)`` stands.  ``layout='auto'`` (default) lets K1 march a
     float4-bricked copy of each bound Buffer (see ComputeKernel._brats; 'linear' binds the buffers
-    as uploaded, like the reference); ``math`` selects the strict or fast arithmetic flavour."""
+    as uploaded, like the reference); ``math`` selects the strict or fast arithmetic flavour;
+    ``skip_empty`` (default on; it changes no bit of the frame) lets the march skip 8^3 macro cells that
+    cannot contribute under the frame's window / overlays — the air around a skull-stripped scan."""
 
     def __init__(self, enable_debug_layers: bool = False, compiler_options: Optional[dict] = None,
-                 layout: str = "auto", math: str = "strict"):
+                 layout: str = "auto", math: str = "strict", skip_empty: bool = True):
         self.torch_device = _r._require_gpu()
         self.default_ext = {"layout": layout, "math": math}
+        self.skip_empty = bool(skip_empty)
 
     def load_program(self, path: Union[str, pathlib.Path], entry_points: Sequence[str]) -> Program:
         for ep in entry_points:
