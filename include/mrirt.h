@@ -179,13 +179,18 @@ typedef struct MrirtVolumeParams {
 typedef enum MrirtVoxelMode {
     MRIRT_VOX_U32X4 = 0,   /* reference: StructuredBuffer<uint4>, one u32 per u8 voxel (app.py:150-153) */
     MRIRT_VOX_U8 = 1,      /* real bytes (1 B/voxel)                                                     */
-    MRIRT_VOX_F32 = 2      /* fp32 grid (build-defined generalisation)                    */
+    MRIRT_VOX_F32 = 2,     /* fp32 grid (build-defined generalisation)                    */
+    MRIRT_VOX_CELL8 = 3    /* 8 B/voxel: the eight bytes of the trilinear cell based at the voxel, built */
+                           /* once by mrirt_build_cell8 — one gather per sample, same bytes, same frame  */
 } MrirtVoxelMode;
 
 /* Drop-in for kernel.dispatch(...) of volume_cs, scripts/volumeRendering/app.py:350-358.
  * volume = gVolumeU8 in `mode`; ext may be NULL (uses cameraMode/orthoHalfHeight/math/outFormat/tiles). */
 int mrirt_render_volume(const MrirtVolumeParams* params, const MrirtRenderExt* ext, const void* volume,
                         uint32_t mode, void* out_rgba, int64_t pitch_px, uint64_t* stats_dev, void* stream);
+/* load time: u8 voxels (src_mode MRIRT_VOX_U8, or the reference's one-u32-per-voxel MRIRT_VOX_U32X4) ->
+ * MRIRT_VOX_CELL8 grid of dims[0]*dims[1]*dims[2] 8-byte elements */
+int mrirt_build_cell8(const void* voxels, uint32_t src_mode, const uint32_t dims[3], void* cell8, void* stream);
 
 /* ------------------------------------------------------------------------------------ */
 /* K3  raymarch_cs                                                                       */

@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "mrirt_render_brats", "mrirt_render_brats_ex", "mrirt_brats_sample_counts", "mrirt_brats_emit_samples",
     "mrirt_render_brats_stream", "mrirt_brick_elems", "mrirt_brick_grid",
     "mrirt_unbrick_grid", "mrirt_vec4_elems", "mrirt_build_vec4_grid", "mrirt_bc4_decode", "mrirt_macro_cells", "mrirt_skip_mask_words",
-    "mrirt_build_macro_max", "mrirt_build_macro_labels", "mrirt_render_brats_skip", "mrirt_render_volume", "mrirt_render_sdf", "mrirt_tiles_for_rank",
+    "mrirt_build_macro_max", "mrirt_build_macro_labels", "mrirt_render_brats_skip", "mrirt_render_volume", "mrirt_build_cell8", "mrirt_render_sdf", "mrirt_tiles_for_rank",
     "mrirt_detile", "mrirt_inr_pack_bytes", "mrirt_inr_pack_weights", "mrirt_inr_forward",
     "mrirt_inr_predict_volume", "mrirt_abi_version", "mrirt_status_string", "mrirt_last_hip_error",
     "mrirt_sizeof",
@@ -33,7 +33,7 @@ OK = 0
 LAYOUT_LINEAR, LAYOUT_BRICK, LAYOUT_VG, LAYOUT_QUAD = 0, 1, 2, 3
 MATH_STRICT, MATH_FAST = 0, 1
 OUT_RGBA32F, OUT_RGBA16F = 0, 1
-VOX_U32X4, VOX_U8, VOX_F32 = 0, 1, 2
+VOX_U32X4, VOX_U8, VOX_F32, VOX_CELL8 = 0, 1, 2, 3
 INR_FOURIER_RELU, INR_SIREN = 0, 1
 
 f32, u32 = C.c_float, C.c_uint32
@@ -175,6 +175,8 @@ def lib() -> C.CDLL:
     l.mrirt_build_macro_labels.restype = i32
     l.mrirt_render_brats_skip.argtypes = [C.POINTER(BratsParams), C.POINTER(RenderExt), C.POINTER(vp), vp, vp, C.POINTER(Skip), vp, i64, vp, vp]
     l.mrirt_render_brats_skip.restype = i32
+    l.mrirt_build_cell8.argtypes = [vp, u32, C.POINTER(u32), vp, vp]
+    l.mrirt_build_cell8.restype = i32
     l.mrirt_bc4_decode.argtypes = [vp, u32, u32, u32, vp, vp]
     l.mrirt_bc4_decode.restype = i32
     l.mrirt_render_volume.argtypes = [C.POINTER(VolumeParams), C.POINTER(RenderExt), vp, u32, vp, i64, vp, vp]

@@ -21,10 +21,19 @@ struct K2Args {
     uint64_t* stats;
 };
 
+// byte / 255.0f, IEEE-exact in three instructions (Markstein, as M<true>::divu: 255's significand is not all
+// ones, so RN(q + (x - q*255) * RN(1/255)) is the correctly rounded quotient; tests check all 256 bytes).  The
+// compiler's own x / 255.0f is a ten-instruction division — eight of them per sample.
+__device__ __forceinline__ float unorm8(uint32_t b) {
+    const float x = (float)b, r = 1.0f / 255.0f;                     // the constant folds to RN(1/255)
+    const float q = x * r;
+    return __builtin_fmaf(__builtin_fmaf(-q, 255.0f, x), r, q);
+}
+
 template <int MODE>
 __device__ __forceinline__ float fetch_k2(const void* __restrict__ vol, uint32_t idx) {
-    if constexpr (MODE == 0) return (float)(static_cast<const uint32_t*>(vol)[idx] & 0xffu) / 255.0f;  // :33-38
-    else if constexpr (MODE == 1) return (float)static_cast<const uint8_t*>(vol)[idx] / 255.0f;
+    if constexpr (MODE == 0) return unorm8(static_cast<const uint32_t*>(vol)[idx] & 0xffu);           // :33-38
+    else if constexpr (MODE == 1) return unorm8(static_cast<const uint8_t*>(vol)[idx]);
     else return static_cast<const float*>(vol)[idx];
 }
 
@@ -79,10 +88,20 @@ __global__ __launch_bounds__(256) void volume_march_kernel(const K2Args a) {
                     t[k] = x - fl;
                 }
                 const uint32_t y0 = p0[1] * sY, y1 = p1[1] * sY, z0 = p0[2] * sZ, z1 = p1[2] * sZ;
-                const float c000 = fetch_k2<MODE>(a.vol, p0[0] + y0 + z0), c100 = fetch_k2<MODE>(a.vol, p1[0] + y0 + z0);
-                const float c010 = fetch_k2<MODE>(a.vol, p0[0] + y1 + z0), c110 = fetch_k2<MODE>(a.vol, p1[0] + y1 + z0);
-                const float c001 = fetch_k2<MODE>(a.vol, p0[0] + y0 + z1), c101 = fetch_k2<MODE>(a.vol, p1[0] + y0 + z1);
-                const float c011 = fetch_k2<MODE>(a.vol, p0[0] + y1 + z1), c111 = fetch_k2<MODE>(a.vol, p1[0] + y1 + z1);
+                float c000, c100, c010, c110, c001, c101, c011, c111;
+                if constexpr (MODE == 3) {
+                    // CELL8: voxel (x,y,z) holds the eight bytes of ITS cell, neighbours clamped as :52-54 —
+                    // one 8-byte gather per sample instead of eight (mrirt_build_cell8)
+                    const uint2 c = static_cast<const uint2*>(a.vol)[p0[0] + y0 + z0];
+                    c000 = unorm8(c.x & 0xffu); c100 = unorm8((c.x >> 8) & 0xffu); c010 = unorm8((c.x >> 16) & 0xffu); c110 = unorm8(c.x >> 24);
+                    c001 = unorm8(c.y & 0xffu); c101 = unorm8((c.y >> 8) & 0xffu); c011 = unorm8((c.y >> 16) & 0xffu); c111 = unorm8(c.y >> 24);
+                    (void)y1; (void)z1;
+                } else {
+                    c000 = fetch_k2<MODE>(a.vol, p0[0] + y0 + z0); c100 = fetch_k2<MODE>(a.vol, p1[0] + y0 + z0);
+                    c010 = fetch_k2<MODE>(a.vol, p0[0] + y1 + z0); c110 = fetch_k2<MODE>(a.vol, p1[0] + y1 + z0);
+                    c001 = fetch_k2<MODE>(a.vol, p0[0] + y0 + z1); c101 = fetch_k2<MODE>(a.vol, p1[0] + y0 + z1);
+                    c011 = fetch_k2<MODE>(a.vol, p0[0] + y1 + z1); c111 = fetch_k2<MODE>(a.vol, p1[0] + y1 + z1);
+                }
                 const float c00 = Mm::lerp(c000, c100, t[0]), c01 = Mm::lerp(c001, c101, t[0]);
                 const float c10 = Mm::lerp(c010, c110, t[0]), c11 = Mm::lerp(c011, c111, t[0]);
                 const float c0 = Mm::lerp(c00, c10, t[1]), c1 = Mm::lerp(c01, c11, t[1]);
@@ -112,6 +131,7 @@ static int launch_k2_mode(const K2Args& a, uint32_t mode, bool half, hipStream_t
     switch (mode) {
         case MRIRT_VOX_U32X4: return launch_k2<STRICT, 0>(a, half, s);
         case MRIRT_VOX_U8: return launch_k2<STRICT, 1>(a, half, s);
+        case MRIRT_VOX_CELL8: return launch_k2<STRICT, 3>(a, half, s);
         default: return launch_k2<STRICT, 2>(a, half, s);
     }
 }
@@ -158,14 +178,48 @@ __global__ __launch_bounds__(256) void sdf_march_kernel(const K3Args a) {
     reinterpret_cast<float4*>(a.out)[oidx] = make_float4(r, g, b, 1.0f);
 }
 
+// u8 voxels -> CELL8 (one thread per voxel): the eight bytes sampleTrilinear reads for the cell based at this
+// voxel, p1 = min(p0 + 1, d - 1) as volume_render.slang:52-54.  Accepts the reference's u32-per-voxel upload too.
+template <bool WIDE_SRC>
+__global__ __launch_bounds__(256) void cell8_build_kernel(const void* __restrict__ src, uint2* __restrict__ dst,
+                                                          uint32_t X, uint32_t Y, uint32_t Z, uint64_t total) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const uint32_t x = (uint32_t)(i % X), y = (uint32_t)((i / X) % Y), z = (uint32_t)(i / ((uint64_t)X * Y));
+    const uint32_t xp = min(x + 1, X - 1), yp = min(y + 1, Y - 1), zp = min(z + 1, Z - 1);
+    auto at = [&](uint32_t xx, uint32_t yy, uint32_t zz) -> uint32_t {
+        const uint64_t k = xx + (uint64_t)X * (yy + (uint64_t)Y * zz);
+        if constexpr (WIDE_SRC) return static_cast<const uint32_t*>(src)[k] & 0xffu;
+        else return static_cast<const uint8_t*>(src)[k];
+    };
+    uint2 c;
+    c.x = at(x, y, z) | (at(xp, y, z) << 8) | (at(x, yp, z) << 16) | (at(xp, yp, z) << 24);
+    c.y = at(x, y, zp) | (at(xp, y, zp) << 8) | (at(x, yp, zp) << 16) | (at(xp, yp, zp) << 24);
+    dst[i] = c;
+}
+
 }  // namespace mrirt
 
 using namespace mrirt;
 
+extern "C" int mrirt_build_cell8(const void* voxels, uint32_t src_mode, const uint32_t dims[3], void* cell8, void* stream) {
+    if (!voxels || !dims || !cell8) return MRIRT_ERR_NULL;
+    if (src_mode != MRIRT_VOX_U32X4 && src_mode != MRIRT_VOX_U8) return MRIRT_ERR_LAYOUT;
+    for (int k = 0; k < 3; ++k) if (dims[k] < 1) return MRIRT_ERR_DIMS;
+    const uint64_t total = (uint64_t)dims[0] * dims[1] * dims[2];
+    if (total >= (1ull << 32)) return MRIRT_ERR_DIMS;
+    const dim3 grid((uint32_t)((total + 255) / 256)), block(256);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (src_mode == MRIRT_VOX_U32X4) hipLaunchKernelGGL(cell8_build_kernel<true>, grid, block, 0, s, voxels, static_cast<uint2*>(cell8), dims[0], dims[1], dims[2], total);
+    else                             hipLaunchKernelGGL(cell8_build_kernel<false>, grid, block, 0, s, voxels, static_cast<uint2*>(cell8), dims[0], dims[1], dims[2], total);
+    MRIRT_HIP(hipGetLastError());
+    return MRIRT_OK;
+}
+
 extern "C" int mrirt_render_volume(const MrirtVolumeParams* p, const MrirtRenderExt* ext, const void* volume,
                                    uint32_t mode, void* out_rgba, int64_t pitch_px, uint64_t* stats_dev, void* stream) {
     if (!p || !volume || !out_rgba) return MRIRT_ERR_NULL;
-    if (mode > MRIRT_VOX_F32) return MRIRT_ERR_LAYOUT;
+    if (mode > MRIRT_VOX_CELL8) return MRIRT_ERR_LAYOUT;
     for (int k = 0; k < 3; ++k) if (p->volDim[k] < 1) return MRIRT_ERR_DIMS;
     if ((uint64_t)p->volDim[0] * p->volDim[1] * p->volDim[2] >= (1ull << 32)) return MRIRT_ERR_DIMS;
     const uint32_t math = ext ? ext->math : (uint32_t)MRIRT_MATH_STRICT;

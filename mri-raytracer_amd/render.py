@@ -267,7 +267,32 @@ def render_brats(params: Mapping[str, Any], intensities: Sequence[Optional[Union
     return o
 
 
-_VOX = {"u32x4": (_lib.VOX_U32X4, torch.int32), "u8": (_lib.VOX_U8, torch.uint8), "f32": (_lib.VOX_F32, torch.float32)}
+_VOX = {"u32x4": (_lib.VOX_U32X4, torch.int32), "u8": (_lib.VOX_U8, torch.uint8), "f32": (_lib.VOX_F32, torch.float32),
+        "cell8": (_lib.VOX_CELL8, torch.int64)}
+
+
+def build_cell8(volume: ArrayLike, dims: Sequence[int], mode: str = "u8", stream=None) -> torch.Tensor:
+    """Load time: u8 voxels (``mode='u8'``) or the reference's one-uint32-per-voxel upload (``'u32x4'``,
+    scripts/volumeRendering/app.py:149-153) -> the CELL8 grid ``render_volume_u8(..., mode='cell8')`` marches:
+    every voxel carries the eight bytes of its trilinear cell, so a sample is ONE 8-byte gather (same frame)."""
+    dev = _require_gpu()
+    code, dt = _VOX[mode]
+    if mode not in ("u8", "u32x4"):
+        raise ValueError("build_cell8 takes u8 or u32x4 voxels")
+    t = torch.as_tensor(volume)
+    if mode == "u32x4" and t.dtype in (torch.uint32, torch.int64):
+        t = t.to(torch.int64).to(torch.int32)
+    if t.dtype != dt:
+        raise TypeError(f"gVolumeU8 ({mode}): expected {dt}, got {t.dtype}")
+    dims = tuple(int(v) for v in dims)
+    n = dims[0] * dims[1] * dims[2]
+    t = t.to(dev).contiguous().reshape(-1)
+    if t.numel() < n:
+        raise ValueError(f"gVolumeU8 holds {t.numel()} < {n} voxels")
+    out = torch.empty(n, dtype=torch.int64, device=dev)
+    d = (C.c_uint32 * 3)(*dims)
+    _lib.check(_lib.lib().mrirt_build_cell8(_ptr(t), code, d, _ptr(out), _stream_ptr(stream)), "mrirt_build_cell8")
+    return out
 
 
 def render_volume_u8(params: Mapping[str, Any], volume: ArrayLike, mode: str = "u32x4",

@@ -177,6 +177,15 @@ class ComputeKernel:
         e = self._out(tex, tc, ext)
         e.pop("layout", None)
         v = vars["gVolumeU8"]
+        if isinstance(v, Buffer) and self.device.default_ext.get("layout") != "linear":
+            # 'auto': march the CELL8 copy of the reference's u32-per-voxel upload (one gather per sample,
+            # same frame); derived once per buffer contents, like K1's bricked copies
+            dims = tuple(int(d) for d in p["volDim"])
+            key = (dims, "cell8")
+            if key not in v._bricked:
+                v._bricked[key] = _r.build_cell8(v.tensor, dims, mode="u32x4")
+            _r.render_volume_u8(p, v._bricked[key], mode="cell8", out=tex.tensor, ext=e)
+            return
         t = v.tensor if isinstance(v, Buffer) else v
         _r.render_volume_u8(p, t, mode="u32x4", out=tex.tensor, ext=e)
 

@@ -334,3 +334,48 @@ def test_bc4_decode_on_device_matches_host_and_oracle():
         dev = volume.bc4_decode_device(data, w, h, d)
         assert dev.dtype == torch.uint8 and dev.numel() == w * h * d
         assert np.array_equal(dev.cpu().numpy(), host)
+
+
+@pytest.mark.parametrize("math", ["strict", "fast"])
+def test_k2_cell8_layout_is_the_same_frame(math):
+    """MRIRT_VOX_CELL8 (one 8-byte gather per sample) against the byte and u32-per-voxel modes and the oracle,
+    on a ragged volume whose last voxels exercise the p1 = min(p0 + 1, d - 1) clamp the build kernel repeats."""
+    import torch
+    import mrirt
+    from mrirt import synth, volume
+    from oracle import oracle_c
+    dims = (37, 29, 23)
+    rng = np.random.default_rng(21)
+    u8 = rng.integers(0, 256, size=dims[::-1], dtype=np.uint8)          # every byte value occurs
+    pk = volume.pack_u8_as_u32x4(u8)
+    p = synth.volume_scene(0, 96, 80, 1.0, 5.0, dims=dims)
+    ext = dict(math=math)
+    t8 = torch.from_numpy(u8.reshape(-1)).cuda()
+    a = mrirt.render_volume_u8(p, t8, mode="u8", ext=ext)
+    for src, mode in ((u8.reshape(-1), "u8"), (pk.view(np.int32).reshape(-1), "u32x4")):
+        c8 = mrirt.render.build_cell8(src, dims, mode)
+        b, st = mrirt.render_volume_u8(p, c8, mode="cell8", ext=ext, stats=True)
+        assert torch.equal(a, b)
+        assert st["live_samples"] > 0
+    if math == "strict":
+        assert np.array_equal(a.cpu().numpy(), oracle_c.volume_cs(p, pk, mode="u32x4"))
+
+
+def test_shim_k2_marches_the_cell8_copy():
+    """The slangpy-shaped dispatch of volume_cs: same frame whether the Device converts (default) or not."""
+    import mrirt.shim as spy
+    from mrirt import synth, volume
+    dims = (40, 36, 28)
+    u8 = np.random.default_rng(2).integers(0, 256, size=dims[::-1], dtype=np.uint8)
+    pk = volume.pack_u8_as_u32x4(u8)
+    p = synth.volume_scene(0, 64, 48, 1.0, 5.0, dims=dims)
+    frames = []
+    for layout in ("auto", "linear"):
+        dev = spy.Device(layout=layout)
+        k = dev.create_compute_kernel(dev.load_program("volume_render.slang", ["volume_cs"]))
+        buf = dev.create_buffer(element_count=pk.size // 4, struct_size=16)
+        buf.copy_from_numpy(pk)
+        tex = dev.create_texture(format=spy.Format.rgba32_float, width=64, height=64)
+        k.dispatch(thread_count=[64, 64, 1], vars={"gOutput": tex, "gParams": p, "gVolumeU8": buf})
+        frames.append(tex.to_numpy())
+    assert np.array_equal(frames[0], frames[1]) and frames[0][..., 0].max() > 0.05

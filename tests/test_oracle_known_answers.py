@@ -177,3 +177,16 @@ def test_bc4_decode_known_block():
     assert list(out[2, 4:]) == pal2[7:3:-1]
     with pytest.raises(RuntimeError):
         onp.bc4_decode(b"\0" * 7, 4, 4, 1)
+
+
+def test_markstein_division_by_255_is_exact_for_every_byte():
+    """csrc/volume_march.hip::unorm8 replaces byte / 255.0f by q = x*r; q + (x - q*255)*r with r = RN(1/255).
+    Emulated here in exact arithmetic (fp64 holds the products of two fp32 exactly): all 256 bytes must give
+    the correctly rounded fp32 quotient."""
+    x = np.arange(256, dtype=np.float32)
+    r = np.float32(1.0) / np.float32(255.0)
+    q = (x * r).astype(np.float32)
+    e = (x.astype(np.float64) - q.astype(np.float64) * 255.0)           # what fma(-q, 255, x) returns, exactly
+    assert np.array_equal(e.astype(np.float32).astype(np.float64), e)   # ... and it is representable
+    got = (e * np.float64(r) + q.astype(np.float64)).astype(np.float32)
+    assert np.array_equal(got, x / np.float32(255.0))

@@ -18,7 +18,7 @@ def timeit(fn, rounds=9):
         e0.record(); fn(); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
     return float(np.median(ts))
 print(f"{'image':>6} {'steps':>5} {'near':>4} {'far':>4} {'mode':>6} {'math':>6} {'ms':>8} {'live Ms':>9} {'Gsamp/s':>8} {'nominal Gs/s':>12} {'err':>9}")
-modes = [m for m in os.environ.get("K2_MODES", "u32x4,u8,f32").split(",")]
+modes = [m for m in os.environ.get("K2_MODES", "u32x4,u8,cell8,f32").split(",")]
 for image, steps, near, far in ((1024, 512, 1.5, 4.5), (1024, 64, 4.3, 4.4), (2048, 512, 1.5, 6.9)):
     p = synth.volume_scene(0, image, steps, near, far, fov_deg=72.0, camera=cam, dims=dims)
     ref = None
@@ -27,7 +27,7 @@ for image, steps, near, far in ((1024, 512, 1.5, 4.5), (1024, 64, 4.3, 4.4), (20
     for mode in modes:
         v = {"u32x4": torch.from_numpy(pk.view(np.int32)).cuda(), "u8": torch.from_numpy(u8).cuda(), "f32": torch.from_numpy(f).cuda()}.get(mode)
         if v is None:
-            v = mrirt.render.upload_k2(u8, dims, mode)
+            v = mrirt.render.build_cell8(u8, dims, "u8")
         for math_ in ("strict", "fast"):
             e = dict(math=math_)
             img, st = mrirt.render_volume_u8(p, v, mode=mode, ext=e, stats=True)
