@@ -70,7 +70,7 @@ typedef enum MrirtLayout {
      *                v[clamp(c+e)] - v[clamp(c-e)] precomputed at load time (mrirt_build_vec4_grid):
      *                a gradient-shaded sample is 8 dwordx4 gathers instead of 32 dword gathers,
      *                bit-identical arithmetic.
-     *        QUAD = (v[x,y], v[x+1,y], v[x,y+1], v[x+1,y+1]) (indices clamped): an unshaded
+     *        QUAD = (v[x,y], v[x,y+1], v[x+1,y], v[x+1,y+1]) (indices clamped): an unshaded
      *                trilinear sample is 2 dwordx4 gathers instead of 8 dword gathers.          */
     MRIRT_LAYOUT_VG = 2,
     MRIRT_LAYOUT_QUAD = 3

@@ -129,7 +129,7 @@ template <bool SHADE> struct Taps<2, SHADE> {        // VG: 8 x (v, dx, dy, dz)
     }
 };
 
-template <> struct Taps<3, false> {                  // QUAD: the z and z+1 xy-quads
+template <> struct Taps<3, false> {                  // QUAD: the z and z+1 xy-quads (x0y0, x0y1, x1y0, x1y1)
     float4 q0, q1;
     template <bool WIDE>
     __device__ __forceinline__ void issue(const void* __restrict__ vbuf, const GridDims& gd, const Cell& s) {
@@ -139,7 +139,11 @@ template <> struct Taps<3, false> {                  // QUAD: the z and z+1 xy-q
     }
     template <bool STRICT>
     __device__ __forceinline__ void eval(const Cell& s, float& v, float*) const {
-        v = trilerp<STRICT>(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, s.fx, s.fy, s.fz);
+        // q = (c00, c01, c10, c11) [x then y]: the x blend of the y0 and y1 rows is one packed lerp per plane
+        using Mm = M<STRICT>;
+        const f32x2 r0 = lerp2<STRICT>(f32x2{ q0.x, q0.y }, f32x2{ q0.z, q0.w }, s.fx);
+        const f32x2 r1 = lerp2<STRICT>(f32x2{ q1.x, q1.y }, f32x2{ q1.z, q1.w }, s.fx);
+        v = Mm::lerp(Mm::lerp(r0.x, r0.y, s.fy), Mm::lerp(r1.x, r1.y, s.fy), s.fz);
     }
 };
 
@@ -216,7 +220,7 @@ __device__ __forceinline__ void composite(const K1Args& a, const float rd[3], co
                                           RayState& r) {
     using Mm = M<STRICT>;
     // wSum (brats_rt.slang:123-130) is the same for every sample: summed on the host
-    if (a.wsum.d > 0.0f) v = Mm::divu(v, a.wsum);
+    if (a.wsum.d > 0.0f && a.wsum.d != 1.0f) v = Mm::divu(v, a.wsum);      // x / 1 == x: skip the three instructions
     float val = satf(Mm::divu(v - a.tfLo, a.wwDiv));                 // :132
     if constexpr (!GAMMA1) val = Mm::pow(val, a.gamma);              // :133
     ++r.nLive;
@@ -386,10 +390,17 @@ struct Stage {
             float sv, gm[3];
             taps[c].template eval<STRICT>(s, sv, gm);
             const float w = a.weight[a.chan[c]];
-            v = Mm::mad(sv, w, v);
-            if constexpr (SHADE) {
+            if (NCH == 1 && w == 1.0f) {
+                // the viewer's weights are 1 (brats_viewer.py:130): 0 + s*1 == s up to the sign of a zero, and no
+                // later step can tell -0 from +0 (val > 0, |g|, g.d are all blind to it) — a uniform branch, no math
+                v = sv;
+                if constexpr (SHADE) { g[0] = gm[0]; g[1] = gm[1]; g[2] = gm[2]; }
+            } else {
+                v = Mm::mad(sv, w, v);
+                if constexpr (SHADE) {
 #pragma unroll
-                for (int k = 0; k < 3; ++k) g[k] = Mm::mad(gm[k], w, g[k]);
+                    for (int k = 0; k < 3; ++k) g[k] = Mm::mad(gm[k], w, g[k]);
+                }
             }
         }
         if constexpr (LABELS) {

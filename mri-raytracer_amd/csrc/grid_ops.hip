@@ -38,7 +38,8 @@ __global__ __launch_bounds__(256) void brick_kernel(const T* __restrict__ src, T
 // destination order, so a wave writes 8 whole 128-B bricks.
 //   VG   = (v, v[x+1]-v[x-1], v[y+1]-v[y-1], v[z+1]-v[z-1]) with neighbour indices clamped to
 //          the grid — exactly the differences the gradient shader forms per corner;
-//   QUAD = (v[x,y], v[x+1,y], v[x,y+1], v[x+1,y+1]) with indices clamped.
+//   QUAD = (v[x,y], v[x,y+1], v[x+1,y], v[x+1,y+1]) with indices clamped: the x0 pair then the x1 pair, so the
+//          x blend of both rows is one packed operation on (xy) and (zw).
 template <bool VG>
 __global__ __launch_bounds__(256) void vec4_build_kernel(const float* __restrict__ src, float4* __restrict__ dst,
                                                          uint32_t X, uint32_t Y, uint32_t Z, uint32_t nbx, uint32_t nby, uint64_t total) {
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(256) void vec4_build_kernel(const float* __restrict
             o.z = at(x, yp, z) - at(x, ym, z);
             o.w = at(x, y, zp) - at(x, y, zm);
         } else {
-            o = make_float4(at(x, y, z), at(xp, y, z), at(x, yp, z), at(xp, yp, z));
+            o = make_float4(at(x, y, z), at(x, yp, z), at(xp, y, z), at(xp, yp, z));
         }
     }
     dst[e] = o;
