@@ -55,6 +55,7 @@ struct K1Args {
     uint32_t mX, mXY;             // macro cells per row / per slice
     void* out;
     uint64_t* stats;
+    ExpConsts ec;                 // fp64 constants of the strict exp, SGPR-resident
 };
 
 template <bool STRICT>
@@ -225,7 +226,8 @@ __device__ __forceinline__ void composite(const K1Args& a, const float rd[3], co
     if constexpr (!GAMMA1) val = Mm::pow(val, a.gamma);              // :133
     ++r.nLive;
     if (val > 0.0f) {
-        const float alpha = 1.0f - Mm::exp(-(val * a.intensityAlpha) * a.stepSize);
+        const float ex = -(val * a.intensityAlpha) * a.stepSize;
+        const float alpha = 1.0f - (SHADE ? Mm::exp_lit(ex) : Mm::exp(ex, a.ec));
         float emis = val;
         if constexpr (SHADE) {
             // headlight Blinn-Phong on the lattice gradient (build-defined extension):
@@ -251,7 +253,7 @@ __device__ __forceinline__ void composite(const K1Args& a, const float rd[3], co
     if (LABELS && a.showSeg != 0) {                                  // :143-151
         const uint32_t l = lb.seg;
         if (l > 0 && l < 8) {
-            const float alpha = 1.0f - Mm::exp(-a.lut[l][3] * a.stepSize);
+            const float alpha = 1.0f - Mm::exp(-a.lut[l][3] * a.stepSize, a.ec);
             const float at = alpha * r.T;
             r.C0 += at * a.lut[l][0]; r.C1 += at * a.lut[l][1]; r.C2 += at * a.lut[l][2];
             r.T *= (1.0f - alpha);
@@ -260,7 +262,7 @@ __device__ __forceinline__ void composite(const K1Args& a, const float rd[3], co
     if (LABELS && a.showPred != 0) {                                 // :154-162
         const uint32_t l = lb.pred;
         if (l > 0 && l < 8) {
-            const float alpha = 1.0f - Mm::exp(-a.lut[l][3] * a.stepSize * 1.5f);
+            const float alpha = 1.0f - Mm::exp(-a.lut[l][3] * a.stepSize * 1.5f, a.ec);
             const float at = alpha * r.T;
             r.C0 += at * a.lut[l][0]; r.C1 += at * a.lut[l][1]; r.C2 += at * a.lut[l][2];
             r.T *= (1.0f - alpha);
@@ -620,6 +622,7 @@ static int prepare(const MrirtBratsParams* p, const MrirtRenderExt* ext, const v
     a.preds = static_cast<const uint32_t*>(preds);
     a.classStream = nullptr; a.rayOffsets = nullptr;
     a.skipMask = nullptr; a.mX = a.mXY = 0;
+    fill_exp_consts(a.ec);
     a.out = nullptr; a.stats = nullptr;
     cfg.layout = layout; cfg.math = math;
     cfg.shade = ext && ext->shadeMode != 0;

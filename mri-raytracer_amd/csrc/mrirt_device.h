@@ -25,22 +25,42 @@ struct UDiv { float d, r; uint32_t exact; };
 // Correctly rounded fp32 exp via fp64: 2^k * P13(x - k ln2).  Same "round a <1-ulp fp64 value
 // once" contract as (float)exp((double)x) on the host, at a third of OCML's instruction count
 // (the argument here is -(val*alpha)*dt: no need for the full double domain).
-__device__ __forceinline__ float exp_f64_to_f32(float xf) {
+// The sixteen fp64 constants come in through the kernel arguments (ExpConsts, filled by the host), i.e. they
+// sit in SGPR pairs and feed v_fma_f64 directly: as literals each one costs a v_mov_b64 into a VGPR pair
+// per use (a 64-bit literal cannot be an operand), ten extra VALU instructions per exp in the march loop.
+struct ExpConsts { double log2e, ln2hi, ln2lo, c[13]; };
+
+__device__ __forceinline__ float exp_f64_to_f32(float xf, const ExpConsts& e) {
     double x = fmin(fmax((double)xf, -200.0), 100.0);        // fp32 result is 0 / inf outside anyway
+    const double k = __builtin_rint(x * e.log2e);
+    double r = __builtin_fma(-k, e.ln2hi, x);                // ln2 hi / lo split
+    r = __builtin_fma(-k, e.ln2lo, r);
+    double p = e.c[0];                                       // 1/13!
+#pragma unroll
+    for (int i = 1; i < 13; ++i) p = __builtin_fma(p, r, e.c[i]);      // ... 1/12!, ..., 1/2!, 1
+    p = __builtin_fma(p, r, 1.0);
+    return (float)__builtin_ldexp(p, (int)k);
+}
+
+// The same polynomial with literal constants (identical values, identical result).  Kept for the
+// gradient-shaded kernel: measured 2-3 % faster there with literals (its time is set by the L1 tag
+// pipeline, and the SGPR operands change the schedule for the worse), 2-3 % slower everywhere else.
+__device__ __forceinline__ float exp_f64_to_f32(float xf) {
+    double x = fmin(fmax((double)xf, -200.0), 100.0);
     const double k = __builtin_rint(x * 1.4426950408889634);
-    double r = __builtin_fma(-k, 6.93147180369123816490e-01, x);       // ln2 hi / lo split
+    double r = __builtin_fma(-k, 6.93147180369123816490e-01, x);
     r = __builtin_fma(-k, 1.90821492927058770002e-10, r);
-    double p = 1.6059043836821613e-10;                                  // 1/13!
-    p = __builtin_fma(p, r, 2.08767569878681e-09);                      // 1/12!
-    p = __builtin_fma(p, r, 2.505210838544172e-08);                     // 1/11!
-    p = __builtin_fma(p, r, 2.755731922398589e-07);                     // 1/10!
-    p = __builtin_fma(p, r, 2.7557319223985893e-06);                    // 1/9!
-    p = __builtin_fma(p, r, 2.48015873015873e-05);                      // 1/8!
-    p = __builtin_fma(p, r, 1.984126984126984e-04);                     // 1/7!
-    p = __builtin_fma(p, r, 1.3888888888888889e-03);                    // 1/6!
-    p = __builtin_fma(p, r, 8.333333333333333e-03);                     // 1/5!
-    p = __builtin_fma(p, r, 4.1666666666666664e-02);                    // 1/4!
-    p = __builtin_fma(p, r, 1.6666666666666666e-01);                    // 1/3!
+    double p = 1.6059043836821613e-10;
+    p = __builtin_fma(p, r, 2.08767569878681e-09);
+    p = __builtin_fma(p, r, 2.505210838544172e-08);
+    p = __builtin_fma(p, r, 2.755731922398589e-07);
+    p = __builtin_fma(p, r, 2.7557319223985893e-06);
+    p = __builtin_fma(p, r, 2.48015873015873e-05);
+    p = __builtin_fma(p, r, 1.984126984126984e-04);
+    p = __builtin_fma(p, r, 1.3888888888888889e-03);
+    p = __builtin_fma(p, r, 8.333333333333333e-03);
+    p = __builtin_fma(p, r, 4.1666666666666664e-02);
+    p = __builtin_fma(p, r, 1.6666666666666666e-01);
     p = __builtin_fma(p, r, 0.5);
     p = __builtin_fma(p, r, 1.0);
     p = __builtin_fma(p, r, 1.0);
@@ -51,7 +71,8 @@ template <> struct M<true> {
     // bit-faithful to oracle_c.c / oracle_np.py: unfused fp32 in the written order; divisions
     // and exp are correctly rounded by construction
     static __device__ __forceinline__ float lerp(float a, float b, float t) { return a + t * (b - a); }
-    static __device__ __forceinline__ float exp(float x) { return exp_f64_to_f32(x); }
+    static __device__ __forceinline__ float exp(float x, const ExpConsts& e) { return exp_f64_to_f32(x, e); }
+    static __device__ __forceinline__ float exp_lit(float x) { return exp_f64_to_f32(x); }
     // x / u.d, IEEE-exact in 3 instructions (Markstein: q = RN(x r); e = x - q d exactly by FMA;
     // RN(q + e r) is the correctly rounded quotient when r = RN(1/d))
     static __device__ __forceinline__ float divu(float x, const UDiv& u) {
@@ -70,7 +91,8 @@ template <> struct M<true> {
 template <> struct M<false> {
     static __device__ __forceinline__ float divu(float x, const UDiv& u) { return x * u.r; }
     static __device__ __forceinline__ float lerp(float a, float b, float t) { return __builtin_fmaf(t, b - a, a); }
-    static __device__ __forceinline__ float exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+    static __device__ __forceinline__ float exp(float x, const ExpConsts&) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+    static __device__ __forceinline__ float exp_lit(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
     static __device__ __forceinline__ float pow(float x, float y) {
         return y == 1.0f ? x : (x > 0.0f ? __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)) : 0.0f);
     }

@@ -34,6 +34,17 @@ inline UDiv make_udiv(float d) {
     return u;
 }
 
+// the constants of exp_f64_to_f32 (mrirt_device.h), in the order its Horner loop consumes them
+inline void fill_exp_consts(ExpConsts& e) {
+    e.log2e = 1.4426950408889634;
+    e.ln2hi = 6.93147180369123816490e-01;
+    e.ln2lo = 1.90821492927058770002e-10;
+    const double c[13] = { 1.6059043836821613e-10, 2.08767569878681e-09, 2.505210838544172e-08, 2.755731922398589e-07,
+                           2.7557319223985893e-06, 2.48015873015873e-05, 1.984126984126984e-04, 1.3888888888888889e-03,
+                           8.333333333333333e-03, 4.1666666666666664e-02, 1.6666666666666666e-01, 0.5, 1.0 };
+    for (int i = 0; i < 13; ++i) e.c[i] = c[i];
+}
+
 // correctly rounded fp32 tan: same expression as the oracle's tanf_cr(0.5f * fovY)
 inline float tan_half_fov(float fovY) { return (float)tan((double)(0.5f * fovY)); }
 
