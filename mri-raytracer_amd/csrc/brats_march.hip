@@ -56,6 +56,7 @@ struct K1Args {
     void* out;
     uint64_t* stats;
     ExpConsts ec;                 // fp64 constants of the strict exp, SGPR-resident
+    uint32_t expSmall;            // intensityAlpha * stepSize <= 1/8: the intensity exp needs no range reduction
 };
 
 template <bool STRICT>
@@ -227,7 +228,10 @@ __device__ __forceinline__ void composite(const K1Args& a, const float rd[3], co
     ++r.nLive;
     if (val > 0.0f) {
         const float ex = -(val * a.intensityAlpha) * a.stepSize;
-        const float alpha = 1.0f - (SHADE ? Mm::exp_lit(ex) : Mm::exp(ex, a.ec));
+        float e;
+        if (a.expSmall) e = SHADE ? Mm::exp_small_lit(ex) : Mm::exp_small(ex, a.ec);      // uniform: |ex| <= 1/8 for every sample
+        else            e = SHADE ? Mm::exp_lit(ex) : Mm::exp(ex, a.ec);
+        const float alpha = 1.0f - e;
         float emis = val;
         if constexpr (SHADE) {
             // headlight Blinn-Phong on the lattice gradient (build-defined extension):
@@ -623,6 +627,7 @@ static int prepare(const MrirtBratsParams* p, const MrirtRenderExt* ext, const v
     a.classStream = nullptr; a.rayOffsets = nullptr;
     a.skipMask = nullptr; a.mX = a.mXY = 0;
     fill_exp_consts(a.ec);
+    a.expSmall = (fabsf(p->intensityAlpha * p->stepSize) <= 0.125f) ? 1u : 0u;   // val is in [0, 1]
     a.out = nullptr; a.stats = nullptr;
     cfg.layout = layout; cfg.math = math;
     cfg.shade = ext && ext->shadeMode != 0;
