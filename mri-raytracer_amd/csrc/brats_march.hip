@@ -6,18 +6,24 @@
 // and the wave leaves the loop (s_cbranch_execz) when its last lane has terminated (t >= t1 or
 // T <= 0.01), so every lane stops accumulating exactly where the scalar shader does.
 //
-// What bounds it (profiles/r01_*): not HBM bytes.  With dword gathers it was the vector L1's tag
-// rate (~36 line accesses per wave-level gather); with one 16-byte gather per corner it is the
-// serial chain  gather -> trilerp -> exp -> T test -> next gather.  Hence
+// What bounds it (profiles/r01_*): not HBM bytes.  With dword gathers it was the vector
+// L1's tag pipeline (~36 line look-ups per wave-level gather); the shaded float4 kernel still saturates
+// it (0.99 look-ups per clock per CU: a sample's cell straddles ~3.4 of the 128-B lines and the kernel makes
+// 3.75 look-ups per sample) with VALU issue at 83 %; the unshaded QUAD kernel is VALU-bound (99.8 %) while
+// drawing 4-4.6 TB/s from HBM.  How it got there:
 //   * layouts where every gather brings 16 useful bytes from a 128-B 2x2x2-voxel brick
 //     (VG = value + lattice gradient, QUAD = the four xy neighbours);
-//   * a software-pipelined loop (march_pipe_kernel): the gathers of step k+1 are issued before
+//   * a software-pipelined loop (brats_march_pipe_kernel): the gathers of step k+1 are issued before
 //     step k is composited.  They are speculative only in that the ray may end at step k; the
 //     addresses are clamped into the grid, so the extra fetch is harmless;
-//   * one packet per workgroup (64 threads), so a finished packet's wave slot refills at once.
+//   * one packet per workgroup (64 threads), so a finished packet's wave slot refills at once, and
+//     16-pixel bands of packets interleaved over the 8 XCDs (every XCD gets the same mix of long and short rays);
+//   * instruction diet for STRICT math: Markstein divisions, a trimmed fp64 exp with SGPR constants,
+//     packed-pair trilinear blends, 32-bit cell offsets, specialisations for gamma == 1 / no overlays.
 //
 // Template axes: STRICT (bit-faithful to the oracle / FAST: FMA + hardware exp2, rcp), LAYOUT
-// (0 linear, 1 4x4x2 fp32 bricks, 2 VG, 3 QUAD), SHADE (lattice-gradient Blinn-Phong extension).
+// (0 linear, 1 4x4x2 fp32 bricks, 2 VG, 3 QUAD), SHADE (lattice-gradient Blinn-Phong extension); the
+// pipelined kernel adds NCH (modalities), GAMMA1, LABELS, SKIP (exact empty-space skipping).
 #include "mrirt_host.h"
 
 namespace mrirt {

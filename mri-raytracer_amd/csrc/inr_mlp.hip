@@ -12,13 +12,17 @@
 // the weights are pre-packed in the same permuted order (mrirt_inr_pack_weights), one 1-KiB fragment
 // per (out tile, k step): an A fragment is one 16-byte read per lane.
 //
-// Work split: a workgroup is 8 waves (2 per SIMD, so one wave's activations overlap the other's
-// MFMAs); each wave owns 32 points.  The weights of up to four out tiles (<= 64 KiB) are a "chunk":
-// chunks are consecutive in the packed image and are staged one chunk ahead by LDS-DMA
+// Work split: a workgroup is 8 waves (2 per SIMD: one wave's DMA / LDS waits are covered by the other's
+// MFMAs); each wave owns 32 points of a 256-point batch, and the workgroup is PERSISTENT: it walks batches
+// round-robin and the weight stream is cyclic (the head chunk stages the next batch's first chunk), so
+// launch, bias staging and DMA latency are paid once.  The weights of up to four out tiles (<= 64 KiB) are a
+// "chunk": chunks are consecutive in the packed image and are staged one chunk ahead by LDS-DMA
 // (global_load_lds, one 1-KiB fragment per wave-instruction into a lane-linear image; double buffer,
-// one barrier per chunk), then read by all 8 waves with conflict-free ds_read_b128.  Weight traffic
-// from L2 is thus one pass of the network per 256 points, and the biases sit in LDS too, so the
-// loop's only vector-memory traffic is the DMA.
+// one barrier per chunk; the pieces are dealt through the MFMA stream, right after each tile's bias read),
+// then read by all 8 waves with conflict-free ds_read_b128 through a four-deep register ring.  The
+// accumulator starts at the bias and the layer scale is folded into the packed weights, so an activation is
+// v_sin_f32 (or half a v_pk_max_f32) plus the packed bf16 convert, sliced under the next tile's MFMAs.
+// Layer-0 inputs: a per-workgroup LDS table of feature descriptors applied to the wave's staged raw inputs.
 //
 // Precision: bf16 operands, fp32 accumulate.  The FIRST layer sees raw coordinates and Fourier
 // features (sin(pi k c), k <= 16) and, for the SIREN, a 30x frequency scale, so its inputs and weights
