@@ -103,3 +103,36 @@ def test_inr_argument_errors(env):
         mrirt.inr.pack_mlp(bad, mrirt.inr.KIND_RAW_RELU)          # hidden 48 unsupported
     with pytest.raises(ValueError):
         mrirt.inr.pack_mlp(bad[:1], mrirt.inr.KIND_RAW_RELU)      # no hidden layer
+    many = [{"W": rng.random((3 + 9, 64)).astype(np.float32), "b": np.zeros(64, np.float32)},
+            {"W": rng.random((64, 4)).astype(np.float32), "b": np.zeros(4, np.float32)}]
+    with pytest.raises(ValueError):
+        mrirt.inr.pack_mlp(many, mrirt.inr.KIND_SIREN, 0, 9)      # more than 8 modalities staged per point
+
+
+@pytest.mark.parametrize("kind_name", ["siren", "fourier"])
+def test_logits_do_not_depend_on_batch_position(env, kind_name):
+    """The persistent workgroups walk 256-point batches; a point's logits must be the same bits wherever it
+    lands: alone (n = 1), at a ragged tail (n = 257), deep inside a launch spanning several batches per
+    workgroup, and duplicated across batches."""
+    import torch
+    mrirt = env["mrirt"]
+    inr = mrirt.inr
+    rng = np.random.default_rng(17)
+    if kind_name == "siren":
+        dims, kind, K, M = [7, 256, 256, 4], inr.KIND_SIREN, 0, 4
+    else:
+        dims, kind, K, M = [3 + 6 * 4 + 4, 64, 64, 64, 4], inr.KIND_FOURIER_RELU, 4, 4
+    params = [{"W": (rng.standard_normal((dims[i], dims[i + 1])) * (0.3 if i else 0.1)).astype(np.float32),
+               "b": (rng.standard_normal(dims[i + 1]) * 0.1).astype(np.float32)} for i in range(len(dims) - 1)]
+    net = inr.pack_mlp(params, kind, K, M)
+    n = 300_000                                           # > 256 workgroups x 256 points x 4 resident
+    coords = (torch.rand((n, 3), device="cuda") * 2 - 1).contiguous()
+    feats = torch.rand((n, M), device="cuda").contiguous()
+    full, cls = inr._forward(net, coords, feats, n, True, True)
+    assert torch.equal(cls.long(), full.argmax(dim=1))
+    for lo, hi in ((0, 1), (0, 257), (123_457, 123_458), (255, 1025), (n - 300, n)):
+        part, _ = inr._forward(net, coords[lo:hi].contiguous(), feats[lo:hi].contiguous(), hi - lo, True, False)
+        assert torch.equal(part, full[lo:hi]), (lo, hi)
+    twice_c, twice_f = torch.cat([coords[:1000]] * 3), torch.cat([feats[:1000]] * 3)
+    rep, _ = inr._forward(net, twice_c.contiguous(), twice_f.contiguous(), 3000, True, False)
+    assert torch.equal(rep[:1000], rep[1000:2000]) and torch.equal(rep[:1000], rep[2000:]) and torch.equal(rep[:1000], full[:1000])
