@@ -121,3 +121,24 @@ def test_skip_speeds_up_a_sparse_volume():
     assert torch.equal(f_plain, f_skip)
     print(f"\n256^3 blob in air, 512^2 x 384 steps, VG shaded strict: plain {t_plain:.3f} ms, skipping {t_skip:.3f} ms")
     assert t_skip < 0.85 * t_plain
+
+
+def test_skip_with_tile_sharding():
+    """Tiles of three 'ranks' rendered with skipping reassemble to the plain whole frame."""
+    import torch
+    import mrirt
+    from mrirt import synth, tiles
+    n, image = 64, 192
+    vols, _ = head_in_air(n, seed=4)
+    p = synth.brats_scene(n, image, 160, channels=1, intensity_alpha=6.0)
+    p["wl"], p["ww"] = np.float32(0.45), np.float32(0.7)
+    ext = dict(synth.SHADE_EXT, layout="vg")
+    g = mrirt.upload_grid(vols[0], (n, n, n), "vg")
+    whole = mrirt.render_brats(p, [g], ext=ext)
+    world, tile = 3, 64
+    parts = [mrirt.render_brats(p, [g], ext=tiles.shard_ext(ext, r, world, tile), skip=True) for r in range(world)]
+    max_local = tiles.local_tile_count(image, image, tile, 0, world)
+    gathered = torch.zeros((world, max_local, tile, tile, 4), device="cuda")
+    for r, t in enumerate(parts):
+        gathered[r, :t.shape[0]] = t
+    assert torch.equal(mrirt.detile(gathered, image, image, tile, world), whole)
