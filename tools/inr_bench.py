@@ -7,7 +7,10 @@ import torch, mrirt
 from mrirt import inr
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 512 * 512 * 256
 rng = np.random.default_rng(0)
+ZERO = os.environ.get("INR_ZERO") == "1"      # DVFS probe: the same instruction stream on all-zero operands
 def net(dims):
+    if ZERO:
+        return [{"W": np.zeros((dims[i], dims[i+1]), np.float32), "b": np.zeros(dims[i+1], np.float32)} for i in range(len(dims) - 1)]
     return [{"W": (rng.uniform(-1, 1, (dims[i], dims[i+1])) * math.sqrt(6 / (dims[i] + dims[i+1]))).astype(np.float32),
              "b": np.zeros(dims[i+1], np.float32)} for i in range(len(dims) - 1)]
 cases = {"siren 7-4x256-4": ([7] + [256] * 4 + [4], inr.KIND_SIREN, 0, 4),
@@ -15,6 +18,8 @@ cases = {"siren 7-4x256-4": ([7] + [256] * 4 + [4], inr.KIND_SIREN, 0, 4),
          "fourier 31-4x64-4": ([31] + [64] * 4 + [4], inr.KIND_FOURIER_RELU, 4, 4)}
 coords = torch.rand((n, 3), device="cuda") * 2 - 1
 feats = torch.rand((n, 4), device="cuda")
+if ZERO:
+    coords.zero_(); feats.zero_()
 out = torch.empty(n, dtype=torch.int16, device="cuda")
 import ctypes as C
 from mrirt import _lib
