@@ -24,10 +24,10 @@
 // v_sin_f32 (or half a v_pk_max_f32) plus the packed bf16 convert, sliced under the next tile's MFMAs.
 // Layer-0 inputs: a per-workgroup LDS table of feature descriptors applied to the wave's staged raw inputs.
 //
-// Precision: bf16 operands, fp32 accumulate.  The FIRST layer sees raw coordinates and Fourier
-// features (sin(pi k c), k <= 16) and, for the SIREN, a 30x frequency scale, so its inputs and weights
-// are split hi + lo in bf16 and three products are accumulated (hi*hi + hi*lo + lo*hi: ~16 mantissa
-// bits).  Hidden layers use plain bf16.
+// Precision: bf16 operands, fp32 accumulate.  A SIREN's FIRST layer scales its inputs by w0 = 30 before a
+// sine, so its inputs and weights are split hi + lo in bf16 and three products are accumulated
+// (hi*hi + hi*lo + lo*hi: ~16 mantissa bits).  A ReLU net's first layer (coordinates, sin(pi k c) features,
+// z-scored intensities) and every hidden layer use plain bf16.
 #include "mrirt_host.h"
 
 namespace mrirt {
@@ -49,13 +49,14 @@ struct InrLayout {
     uint32_t biasOff[kMaxLayers];                        // offset into the padded bias array
     uint32_t wOff[kMaxLayers];                           // offset into the unpadded fp32 weight array
     uint32_t totalFrags;
+    uint32_t split0;                                     // layer 0 carries hi + lo fragments (SIREN kinds)
     // Folded into the packed weights and the LDS copy of the biases, so that the activation is one
     // instruction on the accumulator: SIREN layers are sin(2 pi . rev) with v_sin_f32 taking revolutions,
     // hence scale = w0 / 2 pi (layer 0), 1 / 2 pi (hidden), 1 (head); ReLU nets: 1 everywhere.
     float scale[kMaxLayers];
 };
 
-// Packed image, in fragment units:  layer 0: [o][t][s][hi,lo]   other layers: [o][t][s]
+// Packed image, in fragment units:  layer 0 of a SIREN: [o][t][s][hi,lo]   every other layer: [o][t][s]
 static int make_layout(const MrirtInrDesc* d, InrLayout& L) {
     if (!d) return MRIRT_ERR_NULL;
     if (d->numLayers < 2 || d->numLayers > kMaxLayers || d->outDim < 1 || d->outDim > 16) return MRIRT_ERR_ARG;
@@ -74,11 +75,12 @@ static int make_layout(const MrirtInrDesc* d, InrLayout& L) {
         L.fragOff[l] = frag; L.biasOff[l] = bias; L.wOff[l] = w;
         const bool sirenNet = d->kind == MRIRT_INR_SIREN || d->kind == 3u, head = l + 1 == d->numLayers;
         L.scale[l] = (!sirenNet || head) ? 1.0f : (float)((l == 0 ? (double)d->w0 : 1.0) / 6.283185307179586);
-        frag += ot * kt * 2 * (l == 0 ? 2 : 1);          // layer 0 stores hi and lo fragments side by side
+        frag += ot * kt * 2 * ((l == 0 && sirenNet) ? 2 : 1);     // split layer 0: hi and lo fragments side by side
         bias += ot * 32;
         w += L.in[l] * L.out[l];
     }
     L.totalFrags = frag;
+    L.split0 = (d->kind == MRIRT_INR_SIREN || d->kind == 3u) ? 1u : 0u;
     return MRIRT_OK;
 }
 
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(256) void inr_pack_kernel(const float* __restrict__
     const uint32_t kt = l == 0 ? L.kt0 : L.hidden / 32;
     uint32_t f = frag - L.fragOff[l];
     bool lo = false;
-    if (l == 0) { lo = (f & 1u) != 0; f >>= 1; }
+    if (l == 0 && L.split0) { lo = (f & 1u) != 0; f >>= 1; }
     const uint32_t s = f & 1u, t = (f >> 1) % kt, o = (f >> 1) / kt;
     const uint32_t r = lane & 31u, h = lane >> 5;
     uint16_t e[8];
@@ -133,7 +135,11 @@ template <int HID, int KT0, bool SIREN>
 __global__ __launch_bounds__(512) void inr_forward_kernel(const InrArgs a) {
     constexpr int KT = HID / 32;                         // k tiles of a hidden-wide input == out tiles of a hidden-wide output
     constexpr int OTC = KT < 4 ? KT : 4;                 // out tiles per chunk (one barrier per chunk)
-    constexpr int F0 = KT0 * 4, FH = KT * 2;             // fragments per out tile: layer 0 (hi+lo) / other layers
+    // The first layer of a SIREN multiplies its inputs by w0 = 30 before a sine, so it runs in split bf16 (hi + lo
+    // operands, three products: ~16 mantissa bits).  A ReLU net's first layer sees coordinates, sin / cos
+    // features and z-scored intensities and is as tolerant of bf16 as its hidden layers: one product.
+    constexpr bool SPLIT = SIREN;
+    constexpr int F0 = KT0 * (SPLIT ? 4 : 2), FH = KT * 2;   // fragments per out tile: layer 0 / other layers
     constexpr int CH0 = OTC * F0, CHH = OTC * FH;        // fragments per chunk
     constexpr int CHMAX = CH0 > CHH ? CH0 : CHH;
     constexpr int PERW = (CHMAX + kInrWaves - 1) / kInrWaves;
@@ -370,13 +376,13 @@ __global__ __launch_bounds__(512) void inr_forward_kernel(const InrArgs a) {
     const int64_t pidx = (batch * kInrWaves + waveS) * 32 + r;
     load_inputs(pidx);
 
-    // ---- layer 0: hi/lo split, three products per k step -------------------------------------------------
+    // ---- layer 0: SIREN: hi/lo split, three products per k step; ReLU nets: one ------------------------------
     {
         const uint32_t b0 = a.L.biasOff[0];
 #pragma unroll
         for (int og = 0; og < KT / OTC; ++og) {
             const int nfragNext = (og + 1 < KT / OTC) ? CH0 : (a.L.numLayers > 2 ? CHH : FH);   // layer 0 / layer 1 / head
-            bf16x8 ring[RD];                             // fragment stream: even = hi, odd = lo of k step f/2
+            bf16x8 ring[RD];                             // fragment stream (SPLIT: even = hi, odd = lo of k step f/2)
 #pragma unroll
             for (int d = 0; d < RD; ++d) if (d < CH0) ring[d] = frag_at(buf, d);
 #pragma unroll
@@ -385,16 +391,21 @@ __global__ __launch_bounds__(512) void inr_forward_kernel(const InrArgs a) {
                 f32x16 acc = bias_tile(b0, o);
 #pragma unroll
                 for (int p = 0; p < KT0 * 2; ++p) {
-                    const int t = p >> 1, s = p & 1, f = oo * F0 + 2 * p, step = oo * KT0 * 2 + p;
+                    const int t = p >> 1, s = p & 1, f = oo * F0 + (SPLIT ? 2 : 1) * p, step = oo * KT0 * 2 + p;
                     if (step % SP0 == 0 && step / SP0 < PERW) {
                         if (og + 1 < KT / OTC) stage_piece(nextFrag, IC<CH0>{}, buf ^ 1, step / SP0);    // folds: og is unrolled
                         else                   stage_piece(nextFrag, IC<CHH>{}, buf ^ 1, step / SP0);
                     }
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[(f + 1) % RD], xin_hi[t][s], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[f % RD], xin_lo[t][s], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[f % RD], xin_hi[t][s], acc, 0, 0, 0);
-                    if (f + RD < CH0) ring[f % RD] = frag_at(buf, f + RD);
-                    if (f + 1 + RD < CH0) ring[(f + 1) % RD] = frag_at(buf, f + 1 + RD);
+                    if constexpr (SPLIT) {
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[(f + 1) % RD], xin_hi[t][s], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[f % RD], xin_lo[t][s], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[f % RD], xin_hi[t][s], acc, 0, 0, 0);
+                        if (f + RD < CH0) ring[f % RD] = frag_at(buf, f + RD);
+                        if (f + 1 + RD < CH0) ring[(f + 1) % RD] = frag_at(buf, f + 1 + RD);
+                    } else {
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[f % RD], xin_hi[t][s], acc, 0, 0, 0);
+                        if (f + RD < CH0) ring[f % RD] = frag_at(buf, f + RD);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 activate(acc, o);
