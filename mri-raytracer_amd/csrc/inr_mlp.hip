@@ -50,13 +50,19 @@ struct InrLayout {
     uint32_t wOff[kMaxLayers];                           // offset into the unpadded fp32 weight array
     uint32_t totalFrags;
     uint32_t split0;                                     // layer 0 carries hi + lo fragments (SIREN kinds)
+    uint32_t aug0;                                       // ... or, for <= 8 inputs, the split lives in the k axis (below)
     // Folded into the packed weights and the LDS copy of the biases, so that the activation is one
     // instruction on the accumulator: SIREN layers are sin(2 pi . rev) with v_sin_f32 taking revolutions,
     // hence scale = w0 / 2 pi (layer 0), 1 / 2 pi (hidden), 1 (head); ReLU nets: 1 everywhere.
     float scale[kMaxLayers];
+    float bscale[kMaxLayers];                            // the biases' share of it: 1 / 2 pi without the w0
 };
 
 // Packed image, in fragment units:  layer 0 of a SIREN: [o][t][s][hi,lo]   every other layer: [o][t][s]
+// Augmented split (a SIREN with <= 8 inputs, i.e. the 7-input net of the notebook): the three products
+// x_hi W_hi + x_lo W_hi + x_hi W_lo are folded into the k axis of ONE 32-deep tile — k step 0 carries
+// [x_hi | x_lo] against [W_hi ; W_hi], k step 1 carries [x_hi] against [W_lo] — two MFMAs per out tile
+// instead of six.
 static int make_layout(const MrirtInrDesc* d, InrLayout& L) {
     if (!d) return MRIRT_ERR_NULL;
     if (d->numLayers < 2 || d->numLayers > kMaxLayers || d->outDim < 1 || d->outDim > 16) return MRIRT_ERR_ARG;
@@ -75,12 +81,15 @@ static int make_layout(const MrirtInrDesc* d, InrLayout& L) {
         L.fragOff[l] = frag; L.biasOff[l] = bias; L.wOff[l] = w;
         const bool sirenNet = d->kind == MRIRT_INR_SIREN || d->kind == 3u, head = l + 1 == d->numLayers;
         L.scale[l] = (!sirenNet || head) ? 1.0f : (float)((l == 0 ? (double)d->w0 : 1.0) / 6.283185307179586);
-        frag += ot * kt * 2 * ((l == 0 && sirenNet) ? 2 : 1);     // split layer 0: hi and lo fragments side by side
+        L.bscale[l] = (!sirenNet || head) ? 1.0f : (float)(1.0 / 6.283185307179586);     // sin(w0 (xW) + b): b is not scaled by w0
+        const bool aug = d->kind == MRIRT_INR_SIREN && d->inDim <= 8;
+        frag += ot * kt * 2 * ((l == 0 && sirenNet && !aug) ? 2 : 1);     // split layer 0: hi and lo fragments side by side
         bias += ot * 32;
         w += L.in[l] * L.out[l];
     }
     L.totalFrags = frag;
-    L.split0 = (d->kind == MRIRT_INR_SIREN || d->kind == 3u) ? 1u : 0u;
+    L.aug0 = (d->kind == MRIRT_INR_SIREN && d->inDim <= 8) ? 1u : 0u;
+    L.split0 = ((d->kind == MRIRT_INR_SIREN || d->kind == 3u) && !L.aug0) ? 1u : 0u;
     return MRIRT_OK;
 }
 
@@ -104,11 +113,18 @@ __global__ __launch_bounds__(256) void inr_pack_kernel(const float* __restrict__
     uint16_t e[8];
 #pragma unroll
     for (uint32_t j = 0; j < 8; ++j) {
-        const uint32_t k = 32 * t + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3u), oc = 32 * o + r;
+        uint32_t k = 32 * t + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3u);
+        const uint32_t oc = 32 * o + r;
+        bool part_lo = lo;
+        if (l == 0 && L.aug0) {                          // k step 0: [W_hi ; W_hi], k step 1: [W_lo]
+            const uint32_t kk = k & 15u, in = L.in[0];
+            part_lo = s == 1;
+            k = s == 0 ? (kk < in ? kk : (kk < 2 * in ? kk - in : 0xffffu)) : (kk < in ? kk : 0xffffu);
+        }
         const float v = (k < L.in[l] && oc < L.out[l]) ? w[L.wOff[l] + k * L.out[l] + oc] * L.scale[l] : 0.0f;
         const uint16_t hi = bf16_bits(v);
         const float hif = __builtin_bit_cast(float, (uint32_t)hi << 16);
-        e[j] = lo ? bf16_bits(v - hif) : hi;
+        e[j] = part_lo ? bf16_bits(v - hif) : hi;
     }
     uint4 q;
     q.x = e[0] | ((uint32_t)e[1] << 16); q.y = e[2] | ((uint32_t)e[3] << 16);
@@ -131,14 +147,15 @@ struct InrArgs {
     int16_t* argmax;
 };
 
-template <int HID, int KT0, bool SIREN>
+template <int HID, int KT0, bool SIREN, bool AUG = false>
 __global__ __launch_bounds__(512) void inr_forward_kernel(const InrArgs a) {
     constexpr int KT = HID / 32;                         // k tiles of a hidden-wide input == out tiles of a hidden-wide output
     constexpr int OTC = KT < 4 ? KT : 4;                 // out tiles per chunk (one barrier per chunk)
     // The first layer of a SIREN multiplies its inputs by w0 = 30 before a sine, so it runs in split bf16 (hi + lo
     // operands, three products: ~16 mantissa bits).  A ReLU net's first layer sees coordinates, sin / cos
     // features and z-scored intensities and is as tolerant of bf16 as its hidden layers: one product.
-    constexpr bool SPLIT = SIREN;
+    // AUG: the split folded into the k axis (<= 8 inputs; see the packed-image note above).
+    constexpr bool SPLIT = SIREN && !AUG;
     constexpr int F0 = KT0 * (SPLIT ? 4 : 2), FH = KT * 2;   // fragments per out tile: layer 0 / other layers
     constexpr int CH0 = OTC * F0, CHH = OTC * FH;        // fragments per chunk
     constexpr int CHMAX = CH0 > CHH ? CH0 : CHH;
@@ -159,7 +176,8 @@ __global__ __launch_bounds__(512) void inr_forward_kernel(const InrArgs a) {
     float4* ldsTab = reinterpret_cast<float4*>(ldsAll + 2 * CHMAX * 64 + kBiasQ);
     float* ldsRaw = reinterpret_cast<float*>(ldsAll + 2 * CHMAX * 64 + kBiasQ + kTabQ);
     // Feature table (inr/inr/model.py:11-23 order: coords, per axis [sin k=1..K, cos k=1..K], modalities):
-    // feature f of a point is  trig ? sin(2 pi (raw[src] * mult + phase)) : raw[src]  with raw = (c0,c1,c2,
+    // feature f of a point is  trig == 1 ? sin(2 pi (raw[src] * mult + phase)) : raw[src]  (trig == 2: the bf16
+    // remainder raw[src] - bf16(raw[src]) of the augmented split)  with raw = (c0,c1,c2,
     // m0..m7, 0).  sin(pi k c) / cos(pi k c) go through v_sin_f32, which takes revolutions: mult = k/2
     // (|.| <= 8 at K = 16), phase 0 / 0.25; its ~1e-6 absolute error is far below the split-bf16
     // resolution of the layer-0 operands.
@@ -181,6 +199,12 @@ __global__ __launch_bounds__(512) void inr_forward_kernel(const InrArgs a) {
                 src = 3 + g;
             }
         }
+        if constexpr (AUG) {                             // slot f = 16 s + kk:  s = 0: [x_hi | x_lo],  s = 1: [x_hi]
+            const uint32_t kk = f & 15u, in = a.L.inDim;
+            src = kRawStride - 1; trig = 0;
+            if (f < 16) { if (kk < in) src = kk; else if (kk < 2 * in) { src = kk - in; trig = 2; } }
+            else if (f < 32 && kk < in) src = kk;
+        }
         ldsTab[f] = make_float4(mult, phase, __builtin_bit_cast(float, src), __builtin_bit_cast(float, trig));
     }
     {   // biases: global -> LDS once, so the loop's only vector-memory traffic is the weight LDS-DMA
@@ -189,7 +213,7 @@ __global__ __launch_bounds__(512) void inr_forward_kernel(const InrArgs a) {
             uint32_t l = 0;
             while (l + 1 < a.L.numLayers && 4 * i >= a.L.biasOff[l + 1]) ++l;
             float4 b = reinterpret_cast<const float4*>(a.bias)[i];
-            const float sc = a.L.scale[l];                      // same fold as the packed weights
+            const float sc = a.L.bscale[l];                     // the fold of the packed weights, minus layer 0's w0
             b.x *= sc; b.y *= sc; b.z *= sc; b.w *= sc;
             ldsAll[2 * CHMAX * 64 + i] = __builtin_bit_cast(uint4, b);
         }
@@ -277,10 +301,12 @@ __global__ __launch_bounds__(512) void inr_forward_kernel(const InrArgs a) {
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const float v = __builtin_bit_cast(uint32_t, d[j].w) ? __builtin_amdgcn_sinf(__builtin_fmaf(x[j], d[j].x, d[j].y)) : x[j];
+                        const uint32_t mode = __builtin_bit_cast(uint32_t, d[j].w);
+                        const float v = mode == 1u ? __builtin_amdgcn_sinf(__builtin_fmaf(x[j], d[j].x, d[j].y)) : x[j];
                         const __bf16 hi = (__bf16)v;
-                        xin_hi[t][s][j] = hi;
-                        xin_lo[t][s][j] = (__bf16)(v - (float)hi);
+                        const __bf16 lo = (__bf16)(v - (float)hi);
+                        xin_hi[t][s][j] = (AUG && mode == 2u) ? lo : hi;
+                        xin_lo[t][s][j] = lo;
                     }
                 }
         } else {
@@ -509,11 +535,12 @@ static int launch_inr_kt0(const InrArgs& a, hipStream_t s) {
     const int64_t groups = (a.n + kInrWaves * 32 - 1) / (kInrWaves * 32);
     const bool siren = a.kind == MRIRT_INR_SIREN || a.kind == 3u;
     void (*kern)(const InrArgs) = a.L.kt0 == 1
-        ? (siren ? inr_forward_kernel<HID, 1, true> : inr_forward_kernel<HID, 1, false>)
-        : (siren ? inr_forward_kernel<HID, 4, true> : inr_forward_kernel<HID, 4, false>);
+        ? (siren ? (a.L.aug0 ? inr_forward_kernel<HID, 1, true, true> : inr_forward_kernel<HID, 1, true, false>)
+                 : inr_forward_kernel<HID, 1, false, false>)
+        : (siren ? inr_forward_kernel<HID, 4, true, false> : inr_forward_kernel<HID, 4, false, false>);
     // persistent workgroups: as many as are resident at once (the 4 x 256 nets: one per CU, 150 KB of LDS)
-    static int resident[2][2] = { { 0, 0 }, { 0, 0 } };
-    int& res = resident[a.L.kt0 == 1 ? 0 : 1][siren ? 1 : 0];
+    static int resident[2][3] = { { 0, 0, 0 }, { 0, 0, 0 } };
+    int& res = resident[a.L.kt0 == 1 ? 0 : 1][siren ? (a.L.aug0 ? 2 : 1) : 0];
     if (res == 0) {
         int dev = 0, cus = 0, perCu = 0;
         MRIRT_HIP(hipGetDevice(&dev));

@@ -136,3 +136,34 @@ def test_logits_do_not_depend_on_batch_position(env, kind_name):
     twice_c, twice_f = torch.cat([coords[:1000]] * 3), torch.cat([feats[:1000]] * 3)
     rep, _ = inr._forward(net, twice_c.contiguous(), twice_f.contiguous(), 3000, True, False)
     assert torch.equal(rep[:1000], rep[1000:2000]) and torch.equal(rep[:1000], rep[2000:]) and torch.equal(rep[:1000], full[:1000])
+
+
+def test_siren_with_device_built_inputs_matches_fp64(env):
+    """KIND_SIREN builds x = (coords, modalities) on the device and, for <= 8 inputs, folds the hi/lo split of
+    the first layer into the k axis (two MFMAs per out tile instead of six).  Against an fp64 evaluation of
+    neumors_inr.ipynb:1165-1178, and against the raw-input SIREN kind (three-product path) fed the same x."""
+    import torch
+    mrirt = env["mrirt"]
+    inr = mrirt.inr
+    rng = np.random.default_rng(23)
+    dims, w0 = [7, 256, 256, 256, 4], 30.0
+    params = []
+    for i in range(len(dims) - 1):
+        bound = (1.0 / dims[i]) if i == 0 else np.sqrt(6.0 / dims[i]) / 1.0
+        params.append({"W": rng.uniform(-bound, bound, (dims[i], dims[i + 1])).astype(np.float32),
+                       "b": rng.uniform(-0.1, 0.1, dims[i + 1]).astype(np.float32)})
+    n = 4096
+    coords = (rng.random((n, 3)) * 2 - 1).astype(np.float32)
+    feats = rng.standard_normal((n, 4)).astype(np.float32)
+    x = np.concatenate([coords, feats], axis=1).astype(np.float64)
+    h = np.sin(w0 * (x @ params[0]["W"].astype(np.float64)) + params[0]["b"])
+    for p in params[1:-1]:
+        h = np.sin(h @ p["W"].astype(np.float64) + p["b"])
+    want = h @ params[-1]["W"].astype(np.float64) + params[-1]["b"]
+    net = inr.pack_mlp(params, inr.KIND_SIREN, 0, 4, w0=w0)
+    got, _ = inr._forward(net, torch.from_numpy(coords).cuda(), torch.from_numpy(feats).cuda(), n, True, False)
+    got = got.cpu().numpy()
+    scale = max(1.0, np.abs(want).max())
+    assert np.abs(got - want).max() <= 3e-2 * scale, np.abs(got - want).max() / scale
+    raw = inr.siren_apply({f"l{i}": {"w": p["W"], "b": p["b"]} for i, p in enumerate(params)}, x.astype(np.float32), w0=w0).cpu().numpy()
+    assert np.abs(got - raw).max() <= 1e-2 * scale
