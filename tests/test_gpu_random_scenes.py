@@ -115,3 +115,22 @@ def test_no_modality_enabled_and_lut_edge_labels(env):
     got, st, ref, aux = _render_both(env, p, vols, lab, np.roll(lab, 3), None, "brick")
     assert np.abs(got - ref).max() <= TOL and st["live_samples"] == aux["live_samples"]
     assert ref[..., :3].max() > 0.1
+
+
+@pytest.mark.parametrize("layout,shade", [("vg", True), ("quad", False)])
+def test_exp_range_specialisation_both_sides_of_the_switch(env, layout, shade):
+    """The strict exp drops its range reduction when intensityAlpha * stepSize <= 1/8 (a per-launch switch): frames
+    just below, at and above the switch must all be the oracle's bits, in the pipelined kernels that use it."""
+    mrirt, synth, oc = env
+    n, image, steps = 40, 72, 96
+    vol = synth.synth_volume(n)
+    g = mrirt.upload_grid(vol, (n, n, n), layout)
+    ext = dict(synth.SHADE_EXT) if shade else {}
+    for target in (0.1249, 0.125, 0.1251, 0.9):
+        p = synth.brats_scene(n, image, steps, channels=1, intensity_alpha=1.0)
+        p["intensityAlpha"] = np.float32(target / float(p["stepSize"]))
+        okeys = ("shadeMode", "ka", "kd", "ks", "specPow2", "gradEps")
+        ref, aux = oc.brats_main(p, [vol], None, None, {k: v for k, v in ext.items() if k in okeys}, return_aux=True)
+        got, st = mrirt.render_brats(p, [g], ext=dict(ext, layout=layout, math="strict"), stats=True)
+        assert np.array_equal(got.cpu().numpy(), ref), target
+        assert st["live_samples"] == aux["live_samples"]
