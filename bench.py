@@ -35,6 +35,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0         # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # same guide: dense bf16 (the 5 PF headline includes 2:1 sparsity)
 BYTES_PER_SAMPLE = 32         # 8 taps x 4 B, one fp32 channel          
 BYTES_PER_SHADED = 192        # + 6 x 8 taps x 4 B central differences  
 BYTES_PER_PIXEL = 16          # fp32 RGBA framebuffer store
@@ -57,6 +58,7 @@ def parse():
     ap.add_argument("--tile", type=int, default=64)
     ap.add_argument("--cpu-rows", type=int, default=-1, help="rows of the frame the CPU baseline renders; 0 = skip, -1 = auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-inr", action="store_true", help="skip the INR (MFMA) side measurement")
     ap.add_argument("--force-exchange", action="store_true",
                     help="N=1 only: still create the RCCL group (world size 1), render compact tiles and run the "
                          "asynchronous all-gather + de-tiling path — a single-GPU rehearsal of the N>1 code")
@@ -72,6 +74,44 @@ def measured_traffic(key):
         return (int(entry["hbm_bytes_per_launch"]), entry.get("on_chip")) if entry else (None, None)
     except (OSError, ValueError, KeyError):
         return None, None
+
+
+def inr_path(dev):
+    """The other half of the north star, measured in the same run: BASELINE config C5's MLP (SIREN 7 -> 4 x 256 -> 4,
+    512^2 x 256 = 67.1 M queries, random weights and inputs resident in HBM) on the bf16 MFMA kernel, against the
+    dense bf16 peak.  HIP events on the launch stream; three untimed launches, five timed."""
+    import ctypes as C
+    import torch
+    import mrirt
+    from mrirt import _lib, inr
+    n = 512 * 512 * 256
+    dims = [7, 256, 256, 256, 256, 4]
+    rng = np.random.default_rng(0)
+    params = [{"W": (rng.uniform(-1, 1, (dims[i], dims[i + 1])) * math.sqrt(6 / (dims[i] + dims[i + 1]))).astype(np.float32),
+               "b": rng.uniform(-0.1, 0.1, dims[i + 1]).astype(np.float32)} for i in range(len(dims) - 1)]
+    net = inr.pack_mlp(params, inr.KIND_SIREN, 0, 4)
+    coords = torch.rand((n, 3), device=dev) * 2 - 1
+    feats = torch.rand((n, 4), device=dev)
+    out = torch.empty(n, dtype=torch.int16, device=dev)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def launch():
+        _lib.check(_lib.lib().mrirt_inr_forward(C.byref(net.desc), C.c_void_p(coords.data_ptr()), C.c_void_p(feats.data_ptr()),
+                                                n, None, C.c_void_p(out.data_ptr()), stream), "mrirt_inr_forward")
+    for _ in range(3):
+        launch()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
+    for e0, e1 in ev:
+        e0.record(); launch(); e1.record()
+    torch.cuda.synchronize()
+    ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))
+    flop = 2 * sum(dims[i] * dims[i + 1] for i in range(len(dims) - 1))
+    tflops = flop * n / (ms * 1e-3) / 1e12
+    return {"workload": "C5 MLP: SIREN 7->4x256->4, 512^2 x 256 = 67.1 M queries, bf16 MFMA, fp32 accumulate",
+            "value": round(n / (ms * 1e-3) / 1e6, 1), "unit": "Mqueries/s", "ms_per_launch": round(ms, 3), "dtype": "bf16",
+            "roofline": {"bound": "mfma", "achieved": round(tflops, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(tflops / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                         "kernel": "inr_forward_kernel", "flop_per_query": flop}}
 
 
 def cpu_baseline(params, vol, ext, rows, n_image):
@@ -238,6 +278,8 @@ def main():
                          "compulsory_bytes_per_launch": grid.nbytes + px * BYTES_PER_PIXEL,   # volume once + framebuffer
                          "bytes_per_sample": BYTES_PER_SAMPLE + (0 if a.no_shade else BYTES_PER_SHADED)},
         }
+        if world == 1 and not a.no_inr:
+            out["inr_path"] = inr_path(dev)
         if not a.no_cpu_baseline and a.cpu_rows != 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(params, vol, ext, min(a.cpu_rows, image), image)
         print(json.dumps(out), flush=True)

@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for C in "${SETS[@]}"; do
   i=$((i+1))
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/set$i -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > $OUT/set$i.log 2>&1 || echo "set $i ($C) failed" >> $OUT/errors.log
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/set$i -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-inr "$@" > $OUT/set$i.log 2>&1 || echo "set $i ($C) failed" >> $OUT/errors.log
 done
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections
