@@ -94,6 +94,13 @@ inline int fill_pixel_map(PixelMap& m, uint32_t width, uint32_t height, int64_t 
         const uint32_t bands = (blocksY + bandRows - 1) / bandRows;
         m.bandBlocks = m.blocksX * bandRows;
         m.chunk = ((bands + kXcds - 1) / kXcds) * m.bandBlocks;
+    } else if (m.tileSize != 0 && bandPx >= blockPx && m.tileSize % bandPx == 0 && m.numBlocks != 0) {
+        // tile mode: a tile's workgroups are row-major inside the tile, so bandPx-high slabs of each tile are
+        // runs of consecutive workgroups; deal THOSE round-robin to the XCDs (a rank's tiles are row-major over
+        // the image: contiguous eighths would again hand the long centre rays to two or three XCDs)
+        m.bandBlocks = (m.tileSize / blockPx) * (bandPx / blockPx);
+        const uint32_t bands = (m.numBlocks + m.bandBlocks - 1) / m.bandBlocks;
+        m.chunk = ((bands + kXcds - 1) / kXcds) * m.bandBlocks;
     }
     return MRIRT_OK;
 }
