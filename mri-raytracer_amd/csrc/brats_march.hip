@@ -48,6 +48,7 @@ struct K1Args {
     float intensityAlpha, gamma;
     uint32_t showSeg, showPred;
     float lut[8][4];
+    float segAlpha[8], predAlpha[8];   // the overlays' per-label opacities (exp of a launch constant: computed on the host)
     float ka, kd, ks, gradEps, ert;
     uint32_t specPow2;
     uint32_t half;           // 1: rgba16_float output
@@ -235,8 +236,11 @@ __device__ __forceinline__ void composite(const K1Args& a, const float rd[3], co
     if (val > 0.0f) {
         const float ex = -(val * a.intensityAlpha) * a.stepSize;
         float e;
-        if (a.expSmall) e = SHADE ? Mm::exp_small_lit(ex) : Mm::exp_small(ex, a.ec);      // uniform: |ex| <= 1/8 for every sample
-        else            e = SHADE ? Mm::exp_lit(ex) : Mm::exp(ex, a.ec);
+        // constants: SGPR operands in the lean kernels; literals where the shading / overlay state already fills
+        // the SGPR file (the 32 extra SGPRs spill there: measured +6 % on the 4-modality + overlay frame)
+        constexpr bool LIT = SHADE || LABELS;
+        if (a.expSmall) e = LIT ? Mm::exp_small_lit(ex) : Mm::exp_small(ex, a.ec);        // uniform: |ex| <= 1/8 for every sample
+        else            e = LIT ? Mm::exp_lit(ex) : Mm::exp(ex, a.ec);
         const float alpha = 1.0f - e;
         float emis = val;
         if constexpr (SHADE) {
@@ -263,7 +267,7 @@ __device__ __forceinline__ void composite(const K1Args& a, const float rd[3], co
     if (LABELS && a.showSeg != 0) {                                  // :143-151
         const uint32_t l = lb.seg;
         if (l > 0 && l < 8) {
-            const float alpha = 1.0f - Mm::exp(-a.lut[l][3] * a.stepSize, a.ec);
+            const float alpha = a.segAlpha[l];                           // 1 - exp(-lut[l].w * dt): seven values per launch, host-made
             const float at = alpha * r.T;
             r.C0 += at * a.lut[l][0]; r.C1 += at * a.lut[l][1]; r.C2 += at * a.lut[l][2];
             r.T *= (1.0f - alpha);
@@ -272,7 +276,7 @@ __device__ __forceinline__ void composite(const K1Args& a, const float rd[3], co
     if (LABELS && a.showPred != 0) {                                 // :154-162
         const uint32_t l = lb.pred;
         if (l > 0 && l < 8) {
-            const float alpha = 1.0f - Mm::exp(-a.lut[l][3] * a.stepSize * 1.5f, a.ec);
+            const float alpha = a.predAlpha[l];                          // 1 - exp(-lut[l].w * dt * 1.5)
             const float at = alpha * r.T;
             r.C0 += at * a.lut[l][0]; r.C1 += at * a.lut[l][1]; r.C2 += at * a.lut[l][2];
             r.T *= (1.0f - alpha);
@@ -623,6 +627,14 @@ static int prepare(const MrirtBratsParams* p, const MrirtRenderExt* ext, const v
     a.intensityAlpha = p->intensityAlpha; a.gamma = p->gamma;
     a.showSeg = p->showSeg; a.showPred = p->showPred;
     for (int i = 0; i < 8; ++i) for (int j = 0; j < 4; ++j) a.lut[i][j] = p->lutColorAlpha[i][j];
+    for (int i = 0; i < 8; ++i) {
+        // brats_rt.slang:147,158 in the oracle's arithmetic: fp32 argument in the written order, exp correctly
+        // rounded through fp64, fp32 subtraction
+        const float xs = -a.lut[i][3] * a.stepSize;
+        const float xp = xs * 1.5f;
+        a.segAlpha[i] = 1.0f - (float)exp((double)xs);
+        a.predAlpha[i] = 1.0f - (float)exp((double)xp);
+    }
     a.ka = ext ? ext->ka : 0.0f; a.kd = ext ? ext->kd : 0.0f; a.ks = ext ? ext->ks : 0.0f;
     a.gradEps = ext ? ext->gradEps : 0.0f;
     a.specPow2 = ext ? ext->specPow2 : 0u;
