@@ -379,3 +379,48 @@ def test_shim_k2_marches_the_cell8_copy():
         k.dispatch(thread_count=[64, 64, 1], vars={"gOutput": tex, "gParams": p, "gVolumeU8": buf})
         frames.append(tex.to_numpy())
     assert np.array_equal(frames[0], frames[1]) and frames[0][..., 0].max() > 0.05
+
+
+def test_c4_full_size_tiles_over_eight_ranks(env):
+    """BASELINE config 4 at full size on one GPU: 512^3, 2048 x 2048, 512 steps, shaded, 64 x 64 tiles dealt to 8
+    'ranks'.  Each rank's compact tile buffer, gathered and de-tiled (the HIP de-tiling kernel), must be the
+    whole-frame render bit for bit, and the ranks' live-sample counts must add up to the whole frame's."""
+    torch, mrirt, synth = env["torch"], env["mrirt"], env["synth"]
+    from mrirt import tiles
+    n, image, steps, world, tile = 512, 2048, 512, 8, 64
+    vol = synth.synth_volume(n)
+    g = mrirt.upload_grid(vol, (n, n, n), "vg")
+    p = synth.brats_scene(n, image, steps, channels=1, intensity_alpha=16.0)
+    ext = dict(synth.SHADE_EXT, layout="vg")
+    whole, sw = mrirt.render_brats(p, [g], ext=ext, stats=True)
+    max_local = tiles.local_tile_count(image, image, tile, 0, world)
+    gathered = torch.zeros((world, max_local, tile, tile, 4), device="cuda")
+    live = shaded = 0
+    for r in range(world):
+        part, st = mrirt.render_brats(p, [g], ext=tiles.shard_ext(ext, r, world, tile), stats=True)
+        assert part.shape == (tiles.local_tile_count(image, image, tile, r, world), tile, tile, 4)
+        gathered[r, :part.shape[0]] = part
+        live, shaded = live + st["live_samples"], shaded + st["shaded_samples"]
+    assert torch.equal(mrirt.detile(gathered, image, image, tile, world), whole)
+    assert live == sw["live_samples"] and shaded == sw["shaded_samples"]
+    assert 0 < live < image * image * steps
+
+
+def test_c2_full_size_against_the_oracle(env):
+    """BASELINE config 2 at full size, the reference's own semantics: 256^3 x 4 modalities + segmentation overlay,
+    512 x 512 perspective, 256 steps.  The C/OpenMP oracle renders the whole frame in a fraction of a second on the
+    GPU box's host, so this one is compared in full: image bits and live-sample count, for the float4 layout the
+    shim picks and for the reference's own linear buffers."""
+    torch, mrirt, synth, oc = env["torch"], env["mrirt"], env["synth"], env["oc"]
+    n, image, steps = 256, 512, 256
+    vols = [synth.synth_volume(n, 1234 + m, phase=0.4 * m) for m in range(4)]
+    lab = synth.synth_labels(n)
+    p = synth.brats_scene(n, image, steps, channels=4, show_seg=True, intensity_alpha=0.4)
+    ref, aux = oc.brats_main(p, vols, lab, None, None, return_aux=True)
+    for layout, lab_layout in (("quad", "brick"), ("linear", "linear")):
+        g = [mrirt.upload_grid(v, (n, n, n), layout) for v in vols]
+        gl = mrirt.upload_grid(lab, (n, n, n), lab_layout)
+        got, st = mrirt.render_brats(p, g, gl, ext=dict(layout=layout, labelLayout=lab_layout), stats=True, skip=layout == "quad")
+        assert np.array_equal(got.cpu().numpy(), ref), layout
+        assert st["live_samples"] == aux["live_samples"]
+        del g, gl
