@@ -390,11 +390,16 @@ struct Stage {
             empty = false;
         }
     }
-    __device__ __forceinline__ void issue(const K1Args& a) {
+    // streamRow / streamValid: C5's class stream (one class per sample of the ray); the fetch of step k+1 is
+    // speculative, so it is made only when that sample exists (t_next < t1)
+    __device__ __forceinline__ void issue(const K1Args& a, int64_t streamRow = 0, bool streamValid = true) {
         if (SKIP && empty) return;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) taps[c].template issue<false>(a.vol[a.chan[c]], a.grid, s);   // grid < 4 GiB (launch())
-        if constexpr (LABELS) fetch_labels(a, s, lb);
+        if constexpr (LABELS) {
+            if (a.classStream != nullptr && !streamValid) { lb.seg = a.showSeg != 0 ? sample_label(a.labels, a.lab, s.q, a.hiLab) : 0u; lb.pred = 0u; }
+            else fetch_labels(a, s, lb, streamRow);
+        }
     }
     template <bool STRICT, bool GAMMA1>
     __device__ __forceinline__ void consume(const K1Args& a, const float rd[3], RayState& r) const {
@@ -440,22 +445,24 @@ __global__ __launch_bounds__(256, (LABELS || SKIP) ? 3 : 4) void brats_march_pip
             float t = t0;
             Stage<LAYOUT, SHADE, NCH, LABELS, SKIP> A, B;
             SkipCursor cur = { 0xffffffffu, false };
+            int64_t row = 0;                                             // C5: next row of this ray in the class stream
+            if constexpr (LABELS) { if (a.classStream != nullptr) row = a.rayOffsets[(int64_t)py * a.map.width + px]; }
             locate<STRICT>(a, ro, rd, t, A.s);
             A.classify(a, cur);
-            A.issue(a);
+            A.issue(a, row++, true);
             while (true) {
                 // invariant: stage A holds the sample at t, and (t < t1 && T > ert) holds
                 float tn = t + a.stepSize;
                 locate<STRICT>(a, ro, rd, tn, B.s);
                 B.classify(a, cur);
-                B.issue(a);                                           // speculative next step
+                B.issue(a, row++, tn < t1);                           // speculative next step
                 A.template consume<STRICT, GAMMA1>(a, rd, r);
                 t = tn;
                 if (!(t < t1 && r.T > a.ert)) break;
                 tn = t + a.stepSize;
                 locate<STRICT>(a, ro, rd, tn, A.s);
                 A.classify(a, cur);
-                A.issue(a);
+                A.issue(a, row++, tn < t1);
                 B.template consume<STRICT, GAMMA1>(a, rd, r);
                 t = tn;
                 if (!(t < t1 && r.T > a.ert)) break;
@@ -539,6 +546,7 @@ struct EmitArgs {
     UDiv zsigma[4];
     float zmu[4];
     double dimM1[3];             // dim - 1 (fp64 divide: the same expression as predict_volume)
+    double rdimM1[3];            // RN(1 / (dim - 1)): Markstein's exact quotient in three fp64 instructions
     const int64_t* offsets;
     float* coords;
     float4* feats;
@@ -557,17 +565,23 @@ __global__ __launch_bounds__(256) void emit_samples_kernel(const K1Args a, const
         Cell s;
         locate<STRICT>(a, ro, rd, t, s);
         float z[4];
+        Taps<LAYOUT, false> taps[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) taps[m].template issue<true>(a.vol[m], a.grid, s);      // all gathers in flight first
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-            Taps<LAYOUT, false> taps;
             float v;
-            taps.template issue<true>(a.vol[m], a.grid, s);
-            taps.template eval<STRICT>(s, v, nullptr);
+            taps[m].template eval<STRICT>(s, v, nullptr);
             z[m] = STRICT ? Mm::divu(v - e.zmu[m], e.zsigma[m]) : (v - e.zmu[m]) * e.zsigma[m].r;
         }
 #pragma unroll
-        for (int k = 0; k < 3; ++k)      // fp64, one rounding: predict_volume's coordinate at lattice points
-            e.coords[row * 3 + k] = (float)(((double)clampf(s.q[k], 0.0f, a.hiLab[k]) / e.dimM1[k]) * 2.0 - 1.0);
+        for (int k = 0; k < 3; ++k) {    // fp64, one rounding: predict_volume's coordinate at lattice points
+            // x / (dim - 1) exactly (Markstein: dim - 1 is a small integer, its significand is never all ones)
+            const double x = (double)clampf(s.q[k], 0.0f, a.hiLab[k]);
+            const double q0 = x * e.rdimM1[k];
+            const double q = __builtin_fma(__builtin_fma(-q0, e.dimM1[k], x), e.rdimM1[k], q0);
+            e.coords[row * 3 + k] = (float)(q * 2.0 - 1.0);
+        }
         e.feats[row] = make_float4(z[0], z[1], z[2], z[3]);
     }
 }
@@ -777,9 +791,9 @@ extern "C" int mrirt_render_brats_stream(const MrirtBratsParams* p, const MrirtR
     if (p->showPred == 0) return MRIRT_ERR_ARG;
     a.classStream = classes; a.rayOffsets = offsets;
     a.out = out_rgba; a.stats = stats_dev;
-    hipStream_t s = static_cast<hipStream_t>(stream);            // the streamed label lives in the general kernel
-    return cfg.math == MRIRT_MATH_STRICT ? launch_layout<true>(a, cfg.layout, cfg.shade, false, s)
-                                         : launch_layout<false>(a, cfg.layout, cfg.shade, false, s);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return cfg.math == MRIRT_MATH_STRICT ? launch_layout<true>(a, cfg.layout, cfg.shade, cfg.pipe, s)
+                                         : launch_layout<false>(a, cfg.layout, cfg.shade, cfg.pipe, s);
 }
 
 extern "C" int mrirt_brats_sample_counts(const MrirtBratsParams* p, const MrirtRenderExt* ext, uint32_t* counts, void* stream) {
@@ -820,7 +834,7 @@ extern "C" int mrirt_brats_emit_samples(const MrirtBratsParams* p, const MrirtRe
     if (rc != MRIRT_OK) return rc;
     EmitArgs e;
     for (int m = 0; m < 4; ++m) { e.zmu[m] = zmu[m]; e.zsigma[m] = make_udiv(zsigma[m]); }
-    for (int k = 0; k < 3; ++k) e.dimM1[k] = (double)(p->dims[k] - 1);
+    for (int k = 0; k < 3; ++k) { e.dimM1[k] = (double)(p->dims[k] - 1); e.rdimM1[k] = 1.0 / e.dimM1[k]; }
     e.offsets = offsets; e.coords = coords; e.feats = reinterpret_cast<float4*>(feats);
     hipStream_t s = static_cast<hipStream_t>(stream);
     return cfg.math == MRIRT_MATH_STRICT ? launch_emit<true>(a, e, cfg.layout, s) : launch_emit<false>(a, e, cfg.layout, s);
