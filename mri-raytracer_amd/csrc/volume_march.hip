@@ -73,7 +73,33 @@ __global__ __launch_bounds__(256) void volume_march_kernel(const K2Args a) {
         const float scale = 4.0f / a.steps;
         const uint32_t nsteps = (uint32_t)a.steps;
         const uint32_t sY = a.dim[0], sZ = a.dim[0] * a.dim[1];
-        for (uint32_t i = 0; i < nsteps; ++i) {
+        // The shader walks all `steps` positions and tests each against the cube (:136); most of them lie outside
+        // it (96 % at the bench geometry).  The positions are a running fp32 sum, so they cannot be jumped to —
+        // but the steps before the ray can possibly have entered need only the three adds, and the steps after
+        // it has certainly left change nothing (the cube is convex).  [iEnter, iExit) is the slab interval of
+        // the exact line, widened by the worst-case drift of the running sum (in steps) plus two.
+        uint32_t iEnter = 0, iExit = nsteps;
+        {
+            float lo = 0.0f, hi = (float)nsteps;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float end = pos[k] + (float)nsteps * sv[k];
+                const float drift = (float)nsteps * 1.2e-7f * fmaxf(fabsf(pos[k]), fabsf(end)) + 1e-6f;
+                if (fabsf(sv[k]) > 1e-30f) {
+                    const float r = 1.0f / sv[k];
+                    const float i0 = (-1.0f - pos[k]) * r, i1 = (1.0f - pos[k]) * r;
+                    const float m = fabsf(drift * r) + 2.0f;
+                    lo = fmaxf(lo, fminf(i0, i1) - m);
+                    hi = fminf(hi, fmaxf(i0, i1) + m);
+                } else if (!(fabsf(pos[k]) < 1.0f + drift)) {
+                    hi = -1.0f;                                        // parallel to this slab and outside it
+                }
+            }
+            if (hi < lo) { iEnter = iExit = 0; }
+            else { iEnter = (uint32_t)floorf(lo); iExit = min(nsteps, (uint32_t)ceilf(hi) + 1u); iEnter = min(iEnter, iExit); }
+        }
+        for (uint32_t i = 0; i < iEnter; ++i) { pos[0] += sv[0]; pos[1] += sv[1]; pos[2] += sv[2]; }
+        for (uint32_t i = iEnter; i < iExit; ++i) {
             const bool inside = pos[0] < 1.0f && pos[1] < 1.0f && pos[2] < 1.0f &&
                                 pos[0] > -1.0f && pos[1] > -1.0f && pos[2] > -1.0f;
             if (inside && accum < 1.0f) {

@@ -134,3 +134,28 @@ def test_exp_range_specialisation_both_sides_of_the_switch(env, layout, shade):
         got, st = mrirt.render_brats(p, [g], ext=dict(ext, layout=layout, math="strict"), stats=True)
         assert np.array_equal(got.cpu().numpy(), ref), target
         assert st["live_samples"] == aux["live_samples"]
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_k2_random_cameras_and_slabs(env, seed):
+    """K2 walks only the steps between the (widened) slab interval of the cube and adds its way to it; whatever the
+    camera, near / far planes, field of view and step count — camera inside the cube, segments that miss it, thousands
+    of steps (the running sum drifts), a zero-length segment — the frame and the live-sample count are the oracle's."""
+    mrirt, synth, oc = env
+    rng = np.random.default_rng(4000 + seed)
+    dims = tuple(int(v) for v in rng.integers(2, 36, 3))
+    u8 = rng.integers(0, 256, size=dims[::-1], dtype=np.uint8)
+    cam = synth.bench_camera(radius=float(rng.choice([0.2, 0.9, 1.6, 3.0, 6.0])), phi_deg=float(rng.uniform(2, 178)),
+                             theta_deg=float(rng.uniform(0, 360)))
+    near = float(rng.choice([0.0, 0.3, 1.5, 4.0]))
+    far = near + float(rng.choice([0.0, 0.05, 1.0, 4.0, 12.0]))
+    steps = int(rng.choice([1, 7, 64, 300, 3000]))
+    p = synth.volume_scene(0, 0, steps, near, far, fov_deg=float(rng.uniform(20, 110)), camera=cam, dims=dims)
+    p["imageSize"] = (np.uint32(int(rng.integers(1, 70))), np.uint32(int(rng.integers(1, 50))))
+    ext = dict(cameraMode=int(rng.integers(0, 2)), orthoHalfHeight=float(rng.uniform(0.4, 1.6)))
+    ref, aux = oc.volume_cs(p, u8, mode="u8", ext={k: ext[k] for k in ("cameraMode", "orthoHalfHeight")}, return_aux=True)
+    img, st = mrirt.render_volume_u8(p, u8.reshape(-1), mode="u8", ext=ext, stats=True)
+    assert np.array_equal(img.cpu().numpy(), ref), (seed, dims, steps, near, far)
+    assert st["live_samples"] == aux["live_samples"]
+    c8 = mrirt.render.build_cell8(u8.reshape(-1), dims, "u8")
+    assert np.array_equal(mrirt.render_volume_u8(p, c8, mode="cell8", ext=ext).cpu().numpy(), ref)
