@@ -147,7 +147,12 @@ struct InrArgs {
     int16_t* argmax;
 };
 
-template <int HID, int KT0, bool SIREN, bool AUG = false>
+constexpr int kResidentFrags = 56;    // RES: the whole packed image (<= 56 KiB) lives in LDS; two workgroups still fit a CU
+
+// RES (small nets: the 4 x 64 network of inr/interactive.ipynb is 36 fragments): the weights are loaded into LDS
+// once per workgroup and stay; the batch loop then has no DMA and no barrier at all — with chunks this small the
+// per-chunk barrier and the DMA latency behind it were most of a batch's time.
+template <int HID, int KT0, bool SIREN, bool AUG = false, bool RES = false>
 __global__ __launch_bounds__(512) void inr_forward_kernel(const InrArgs a) {
     constexpr int KT = HID / 32;                         // k tiles of a hidden-wide input == out tiles of a hidden-wide output
     constexpr int OTC = KT < 4 ? KT : 4;                 // out tiles per chunk (one barrier per chunk)
@@ -170,11 +175,12 @@ __global__ __launch_bounds__(512) void inr_forward_kernel(const InrArgs a) {
     constexpr int kTabQ = 128;                           // one descriptor per layer-0 input feature
     constexpr int kRawQ = kInrWaves * 32 * kRawStride / 4;   // each wave's 32 points x (3 coords, <= 8 mods, a zero)
     // 2 weight buffers (<= 64 KiB each) + biases + feature table + raw inputs: ONE LDS object (G17)
-    __shared__ uint4 ldsAll[2 * CHMAX * 64 + kBiasQ + kTabQ + kRawQ];
+    constexpr int kWQ = (RES ? kResidentFrags : 2 * CHMAX) * 64;     // weight region, in uint4
+    __shared__ uint4 ldsAll[kWQ + kBiasQ + kTabQ + kRawQ];
     uint4 (*lds)[CHMAX * 64] = reinterpret_cast<uint4 (*)[CHMAX * 64]>(ldsAll);
-    const float4* ldsBias = reinterpret_cast<const float4*>(ldsAll + 2 * CHMAX * 64);
-    float4* ldsTab = reinterpret_cast<float4*>(ldsAll + 2 * CHMAX * 64 + kBiasQ);
-    float* ldsRaw = reinterpret_cast<float*>(ldsAll + 2 * CHMAX * 64 + kBiasQ + kTabQ);
+    const float4* ldsBias = reinterpret_cast<const float4*>(ldsAll + kWQ);
+    float4* ldsTab = reinterpret_cast<float4*>(ldsAll + kWQ + kBiasQ);
+    float* ldsRaw = reinterpret_cast<float*>(ldsAll + kWQ + kBiasQ + kTabQ);
     // Feature table (inr/inr/model.py:11-23 order: coords, per axis [sin k=1..K, cos k=1..K], modalities):
     // feature f of a point is  trig == 1 ? sin(2 pi (raw[src] * mult + phase)) : raw[src]  (trig == 2: the bf16
     // remainder raw[src] - bf16(raw[src]) of the augmented split)  with raw = (c0,c1,c2,
@@ -215,7 +221,7 @@ __global__ __launch_bounds__(512) void inr_forward_kernel(const InrArgs a) {
             float4 b = reinterpret_cast<const float4*>(a.bias)[i];
             const float sc = a.L.bscale[l];                     // the fold of the packed weights, minus layer 0's w0
             b.x *= sc; b.y *= sc; b.z *= sc; b.w *= sc;
-            ldsAll[2 * CHMAX * 64 + i] = __builtin_bit_cast(uint4, b);
+            ldsAll[kWQ + i] = __builtin_bit_cast(uint4, b);
         }
     }
 
@@ -235,6 +241,7 @@ __global__ __launch_bounds__(512) void inr_forward_kernel(const InrArgs a) {
     // fetches a full hidden chunk: the packed image carries that much slack, mrirt_inr_pack_bytes), so
     // with 8 | N the piece is unconditional and the MFMA stream stays one basic block.
     auto stage_piece = [&](uint32_t fragStart, auto nfragC, int dstBuf, int i) {
+        if constexpr (RES) return;
         constexpr int N = decltype(nfragC)::value;
         const int f = (int)waveS + i * kInrWaves;                    // scalar: the source is s[base] + lane * 16
         if ((N % kInrWaves == 0) ? (i < N / kInrWaves) : (f < N))
@@ -246,11 +253,22 @@ __global__ __launch_bounds__(512) void inr_forward_kernel(const InrArgs a) {
 #pragma unroll
         for (int i = 0; i < PERW; ++i) stage_piece(fragStart, nfragC, dstBuf, i);
     };
-    auto frag_at = [&](int buf, int f) { return __builtin_bit_cast(bf16x8, lds[buf][f * 64 + lane]); };
+    uint32_t curFrag = a.L.fragOff[0];                   // RES: first fragment of the chunk being read
+    auto frag_at = [&](int buf, int f) {
+        if constexpr (RES) return __builtin_bit_cast(bf16x8, ldsAll[(curFrag + f) * 64 + lane]);
+        else return __builtin_bit_cast(bf16x8, lds[buf][f * 64 + lane]);
+    };
 
     uint32_t nextFrag = a.L.fragOff[0];
     int buf = 0;
-    stage_issue(nextFrag, IC<CH0>{}, 0);
+    if constexpr (RES) {
+        for (uint32_t f = waveS; f < a.L.totalFrags; f += kInrWaves)     // the whole image, once
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(wp) + ((size_t)f << 10) + (lane << 4)),
+                (__attribute__((address_space(3))) void*)(&ldsAll[f * 64]), 16, 0, 0);
+    } else {
+        stage_issue(nextFrag, IC<CH0>{}, 0);
+    }
     nextFrag += CH0;
 
     // layer-0 B operands: this lane's point, features 16s + 8(j>>2) + 4h + (j&3) of k tile t
@@ -385,7 +403,10 @@ __global__ __launch_bounds__(512) void inr_forward_kernel(const InrArgs a) {
     };
     // the chunk prefetched during this chunk's compute becomes current (hipcc drains the LDS-DMA
     // with vmcnt(0) at the barrier)
-    auto next_chunk = [&]() { __syncthreads(); buf ^= 1; };
+    auto next_chunk = [&]() {
+        if constexpr (RES) curFrag = nextFrag;           // nothing is staged, nothing to wait for
+        else { __syncthreads(); buf ^= 1; }
+    };
 
     __syncthreads();                                     // biases and layer-0 chunk 0 are in LDS
 
@@ -526,6 +547,7 @@ __global__ __launch_bounds__(512) void inr_forward_kernel(const InrArgs a) {
     }
     next_chunk();
     nextFrag = a.L.fragOff[0] + CH0;
+    if constexpr (RES) curFrag = a.L.fragOff[0];
     }   // batch
     if (pendIdx >= 0) a.argmax[pendIdx] = pendVal;
 }
@@ -538,17 +560,27 @@ static int launch_inr_kt0(const InrArgs& a, hipStream_t s) {
         ? (siren ? (a.L.aug0 ? inr_forward_kernel<HID, 1, true, true> : inr_forward_kernel<HID, 1, true, false>)
                  : inr_forward_kernel<HID, 1, false, false>)
         : (siren ? inr_forward_kernel<HID, 4, true, false> : inr_forward_kernel<HID, 4, false, false>);
+    bool res = false;
+    if constexpr (HID <= 64) {
+        if (a.L.totalFrags <= (uint32_t)kResidentFrags) {
+            res = true;
+            kern = a.L.kt0 == 1
+                ? (siren ? (a.L.aug0 ? inr_forward_kernel<HID, 1, true, true, true> : inr_forward_kernel<HID, 1, true, false, true>)
+                         : inr_forward_kernel<HID, 1, false, false, true>)
+                : (siren ? inr_forward_kernel<HID, 4, true, false, true> : inr_forward_kernel<HID, 4, false, false, true>);
+        }
+    }
     // persistent workgroups: as many as are resident at once (the 4 x 256 nets: one per CU, 150 KB of LDS)
-    static int resident[2][3] = { { 0, 0, 0 }, { 0, 0, 0 } };
-    int& res = resident[a.L.kt0 == 1 ? 0 : 1][siren ? (a.L.aug0 ? 2 : 1) : 0];
-    if (res == 0) {
+    static int resident[2][2][3] = { { { 0, 0, 0 }, { 0, 0, 0 } }, { { 0, 0, 0 }, { 0, 0, 0 } } };
+    int& nres = resident[res ? 1 : 0][a.L.kt0 == 1 ? 0 : 1][siren ? (a.L.aug0 ? 2 : 1) : 0];
+    if (nres == 0) {
         int dev = 0, cus = 0, perCu = 0;
         MRIRT_HIP(hipGetDevice(&dev));
         MRIRT_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         MRIRT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, kern, kInrWaves * 64, 0));
-        res = (cus > 0 ? cus : 256) * (perCu > 0 ? perCu : 1);
+        nres = (cus > 0 ? cus : 256) * (perCu > 0 ? perCu : 1);
     }
-    const dim3 grid((uint32_t)(groups < res ? groups : res)), block(kInrWaves * 64);
+    const dim3 grid((uint32_t)(groups < nres ? groups : nres)), block(kInrWaves * 64);
     hipLaunchKernelGGL(kern, grid, block, 0, s, a);
     MRIRT_HIP(hipGetLastError());
     return MRIRT_OK;
