@@ -107,6 +107,12 @@ typedef struct MrirtRenderExt {
     uint32_t reserved[2];
 } MrirtRenderExt;
 
+/* Argument checks shared by every K1 entry point (MRIRT_ERR_ARG, nothing is launched): stepSize must be a
+ * finite positive number that still advances t in fp32 at the far end of the box (t + stepSize > t) and may
+ * not cut the box diagonal into more than 2^20 steps; voxelSize finite and > 0; volMin / eye finite.  The
+ * reference's UI clamps its slider to >= 0.001 (inr/viewer/brats_viewer.py:168); the shader itself would
+ * spin.  K2: stepCount finite and <= 2^20, near / far finite.  K3: maxSteps <= 2^20.                      */
+
 /* Drop-in for kernel.dispatch(...) of brats_main, inr/viewer/brats_viewer.py:431-442.
  *   vol[m]  = gIntensity<m>  (fp32, X*Y*Z, LINEAR; may be NULL when volEnabled[m] == 0)
  *   labels  = gLabels, preds = gPreds (uint32 per voxel; may be NULL when showSeg/showPred == 0)

@@ -28,6 +28,8 @@
 
 namespace mrirt {
 
+constexpr uint32_t kMaxStepsPerRay = 1u << 20;   // prepare(): stepSize may not cut the box diagonal finer
+
 struct K1Args {
     Camera cam;
     PixelMap map;
@@ -606,6 +608,31 @@ static int prepare(const MrirtBratsParams* p, const MrirtRenderExt* ext, const v
     if (needVolumes) {
         for (int m = 0; m < 4; ++m) if (p->volEnabled[m] != 0 && !vol[m]) return MRIRT_ERR_NULL;
         if (p->showSeg != 0 && !labels) return MRIRT_ERR_NULL;
+    }
+    {
+        // The march is `while (t < t1 && T > ert) { ...; t += stepSize; }` (brats_rt.slang:117-165) and the C5
+        // count / emit loops have no transmittance exit at all: a step that is not a positive finite number, or
+        // too small to move t in fp32 at the far end of the box, would spin a wave forever.  The reference UI
+        // clamps its slider to >= 0.001 (brats_viewer.py:168); an API caller gets an error code instead of a
+        // hung GPU.  Also bounded: the step count of the box diagonal (kMaxStepsPerRay), so that a frame is a
+        // finite amount of work.
+        const float h = p->stepSize;
+        if (!(h > 0.0f) || !isfinite(h)) return MRIRT_ERR_ARG;
+        double diag2 = 0.0, dist2 = 0.0;
+        for (int k = 0; k < 3; ++k) {
+            if (!(p->voxelSize[k] > 0.0f) || !isfinite(p->voxelSize[k]) || !isfinite(p->volMin[k]) || !isfinite(p->eye[k]))
+                return MRIRT_ERR_ARG;
+            const double ext = (double)p->voxelSize[k] * (double)p->dims[k];
+            const double c = (double)p->volMin[k] + 0.5 * ext - (double)p->eye[k];
+            diag2 += ext * ext; dist2 += c * c;
+        }
+        double tMax = sqrt(dist2) + sqrt(diag2);                     // no sample lies farther along any ray
+        if (ext && ext->cameraMode == 1u)                            // orthographic origins are offset from the eye
+            tMax += fabs((double)ext->orthoHalfHeight) * (1.0 + (double)p->imageSize[0] / fmax(1.0, (double)p->imageSize[1]));
+        if (p->farT > 0.0f && isfinite(p->farT)) tMax = fmin(tMax, (double)p->farT);
+        const float tFar = (float)tMax;
+        if (!isfinite(tFar) || !(tFar + h > tFar)) return MRIRT_ERR_ARG;          // t += stepSize must advance
+        if (sqrt(diag2) / (double)h > (double)kMaxStepsPerRay) return MRIRT_ERR_ARG;
     }
     fill_camera(a.cam, p->eye, p->U, p->V, p->W, p->fovY, p->imageSize[0], p->imageSize[1], ext, false);
     // XCD-interleaved bands of 16 px by default (variant bit 3: contiguous run per XCD; bits 4-5: 8/32/64 px)

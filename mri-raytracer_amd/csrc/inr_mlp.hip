@@ -28,6 +28,8 @@
 // sine, so its inputs and weights are split hi + lo in bf16 and three products are accumulated
 // (hi*hi + hi*lo + lo*hi: ~16 mantissa bits).  A ReLU net's first layer (coordinates, sin(pi k c) features,
 // z-scored intensities) and every hidden layer use plain bf16.
+#include <atomic>
+
 #include "mrirt_host.h"
 
 namespace mrirt {
@@ -571,14 +573,19 @@ static int launch_inr_kt0(const InrArgs& a, hipStream_t s) {
         }
     }
     // persistent workgroups: as many as are resident at once (the 4 x 256 nets: one per CU, 150 KB of LDS)
-    static int resident[2][2][3] = { { { 0, 0, 0 }, { 0, 0, 0 } }, { { 0, 0, 0 }, { 0, 0, 0 } } };
-    int& nres = resident[res ? 1 : 0][a.L.kt0 == 1 ? 0 : 1][siren ? (a.L.aug0 ? 2 : 1) : 0];
+    // cached per device and kernel family; a relaxed atomic: two threads racing here compute the same number
+    constexpr int kMaxDev = 16;
+    static std::atomic<int> resident[kMaxDev][2][2][3];
+    int dev = 0;
+    MRIRT_HIP(hipGetDevice(&dev));
+    std::atomic<int>& slot = resident[dev >= 0 && dev < kMaxDev ? dev : 0][res ? 1 : 0][a.L.kt0 == 1 ? 0 : 1][siren ? (a.L.aug0 ? 2 : 1) : 0];
+    int nres = (dev >= 0 && dev < kMaxDev) ? slot.load(std::memory_order_relaxed) : 0;
     if (nres == 0) {
-        int dev = 0, cus = 0, perCu = 0;
-        MRIRT_HIP(hipGetDevice(&dev));
+        int cus = 0, perCu = 0;
         MRIRT_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         MRIRT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, kern, kInrWaves * 64, 0));
         nres = (cus > 0 ? cus : 256) * (perCu > 0 ? perCu : 1);
+        if (dev >= 0 && dev < kMaxDev) slot.store(nres, std::memory_order_relaxed);
     }
     const dim3 grid((uint32_t)(groups < nres ? groups : nres)), block(kInrWaves * 64);
     hipLaunchKernelGGL(kern, grid, block, 0, s, a);

@@ -251,6 +251,9 @@ extern "C" int mrirt_render_volume(const MrirtVolumeParams* p, const MrirtRender
     const uint32_t math = ext ? ext->math : (uint32_t)MRIRT_MATH_STRICT;
     const uint32_t fmt = ext ? ext->outFormat : (uint32_t)MRIRT_OUT_RGBA32F;
     if (math > MRIRT_MATH_FAST || fmt > MRIRT_OUT_RGBA16F) return MRIRT_ERR_LAYOUT;
+    // the loop runs uint(max(1, stepCount)) times per pixel (volume_render.slang:131): bound it, and refuse NaN / inf
+    if (!isfinite(p->stepCount) || p->stepCount > (float)(1u << 20)) return MRIRT_ERR_ARG;
+    if (!isfinite(p->nearPlane) || !isfinite(p->farPlane)) return MRIRT_ERR_ARG;
     K2Args a;
     fill_camera(a.cam, p->eye, p->U, p->V, p->W, p->fovY, p->imageSize[0], p->imageSize[1], ext, false);
     // 16x16-pixel workgroups, one workgroup row per band, bands interleaved over the XCDs (load balance)
@@ -270,6 +273,7 @@ extern "C" int mrirt_render_volume(const MrirtVolumeParams* p, const MrirtRender
 extern "C" int mrirt_render_sdf(const MrirtSdfParams* p, uint32_t width, uint32_t height,
                                 float* out_rgba, int64_t pitch_px, void* stream) {
     if (!p || !out_rgba) return MRIRT_ERR_NULL;
+    if (p->maxSteps > (1u << 20)) return MRIRT_ERR_ARG;             // raymarch.slang:70: `i < maxSteps` iterations per pixel
     K3Args a;
     fill_camera(a.cam, p->gEye, p->gU, p->gV, p->gW, p->fovY, width, height, nullptr, true);
     int rc = fill_pixel_map(a.map, width, height, pitch_px, nullptr);

@@ -40,10 +40,10 @@ def model_load(npz_path, config_override: Optional[Dict[str, Any]] = None) -> Tu
     """
     path = pathlib.Path(npz_path).expanduser().resolve()
     if not path.is_file():
-        raise FileNotFoundError(f"NPZ file not found: {path}")
+        raise FileNotFoundError(f"no checkpoint archive at {path}")
     cfg_path = path.with_name(f"{path.stem}_info.json")
     if not cfg_path.is_file():
-        raise FileNotFoundError(f"Config JSON not found next to NPZ: {cfg_path}")
+        raise FileNotFoundError(f"the sidecar {cfg_path.name} (training config) is missing beside {path.name}")
     allow_pickle = bool((config_override or {}).get("ALLOW_PICKLE", False))
     with np.load(str(path), allow_pickle=allow_pickle) as z:
         names = list(z.files)
@@ -59,13 +59,13 @@ def model_load(npz_path, config_override: Optional[Dict[str, Any]] = None) -> Tu
                                  "only for checkpoints you trust") from exc
             if arr.dtype == object:
                 if arr.ndim != 0 and arr.size != 1:
-                    raise ValueError(f"'{key}' in {path} is an object array with shape {arr.shape}; "
-                                     "expected a single serialized object.")
+                    raise ValueError(f"{path}: entry '{key}' holds {arr.size} pickled objects (shape {arr.shape}), "
+                                     "a checkpoint stores exactly one parameter list")
                 params = arr.item()
             else:
                 params = arr
         else:
-            raise KeyError(f"Could not find 'params' key in {path}; available keys: {names}")
+            raise KeyError(f"{path} has neither a 'params' entry nor W_i/b_i arrays (entries: {names})")
     config = json.loads(cfg_path.read_text())
     if config_override is not None:
         config = {**config, **{k: v for k, v in config_override.items() if k != "ALLOW_PICKLE"}}
@@ -186,7 +186,7 @@ def predict_volume(params, case_data: Dict[str, Any], fourier_freqs: int, chunk:
     hwd = (C.c_uint32 * 3)(H, W, D)
     rc = _lib.lib().mrirt_inr_predict_volume(C.byref(net.desc), _ptr(mods), hwd, _ptr(pred), _stream_ptr(None))
     _lib.check(rc, "mrirt_inr_predict_volume")
-    return pred, case_data.get("seg")
+    return pred, case_data["seg"]
 
 
 def render_brats_inr(params, intensities, net: PackedMLP, zmu, zsigma, labels=None, out=None, ext=None,

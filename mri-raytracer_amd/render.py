@@ -6,6 +6,7 @@ without a GPU (or without the built library) these functions raise.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 from dataclasses import dataclass
 from typing import Any, Dict, Mapping, Optional, Sequence, Tuple, Union
@@ -29,6 +30,14 @@ def _require_gpu() -> torch.device:
 def _stream_ptr(stream) -> C.c_void_p:
     s = stream if stream is not None else torch.cuda.current_stream()
     return C.c_void_p(s.cuda_stream if hasattr(s, "cuda_stream") else int(s))
+
+
+def _on_stream(stream):
+    """Context that makes `stream` torch's current stream (allocations and host->device copies follow it);
+    a no-op for the default (None) and for raw hipStream_t integers, which torch cannot adopt without owning."""
+    if stream is not None and isinstance(stream, torch.cuda.Stream):
+        return torch.cuda.stream(stream)
+    return contextlib.nullcontext()
 
 
 def _ptr(t: Optional[torch.Tensor]) -> C.c_void_p:
@@ -203,11 +212,13 @@ def _bind_brats(params, intensities, labels, preds, ext, dev, pred_stream: bool 
     return P, E, vols, lab, prd
 
 
-_MASKS: dict = {}
+_last_skip_mask: Optional[torch.Tensor] = None
 
 
 def _bind_skip(P, intensities, labels, preds, dev):
-    """MrirtSkip for one call: the macro summaries of the bound Grid objects + a cached mask scratch."""
+    """MrirtSkip for one call: the macro summaries of the bound Grid objects + a mask scratch of this call's own
+    (a few KB from the caching allocator, on the launch stream: skip_mask_kernel rewrites it on every launch, so a
+    scratch shared between calls would be overwritten under a march still reading it on another stream)."""
     S = _lib.Skip()
     keep = []
     for m in range(4):
@@ -225,10 +236,11 @@ def _bind_skip(P, intensities, labels, preds, dev):
             keep.append(g.macro)
     d = (C.c_uint32 * 3)(*[int(v) for v in P.dims])
     words = int(_lib.lib().mrirt_skip_mask_words(d))
-    key = (dev.index, words)
-    if key not in _MASKS:
-        _MASKS[key] = torch.empty(words, dtype=torch.int32, device=dev)
-    S.mask = _MASKS[key].data_ptr()
+    global _last_skip_mask
+    mask = torch.empty(words, dtype=torch.int32, device=dev)
+    S.mask = mask.data_ptr()
+    keep.append(mask)
+    _last_skip_mask = mask          # inspection hook (tests read the fraction of skippable cells); never reused
     return S, keep
 
 
@@ -248,22 +260,27 @@ def render_brats(params: Mapping[str, Any], intensities: Sequence[Optional[Union
     cells that cannot contribute under this call's window, weights and overlays fetch nothing.
     """
     dev = _require_gpu()
-    P, E, vols, lab, prd = _bind_brats(params, intensities, labels, preds, ext, dev)
-    o, pitch = _alloc_out(int(P.imageSize[0]), int(P.imageSize[1]), E, dev, out)
-    vp = (C.c_void_p * 4)(*[C.c_void_p(t.data_ptr()) if t is not None else None for t in vols])
-    st = torch.zeros(2, dtype=torch.int64, device=dev) if stats else None
-    if skip:
-        S, keep = _bind_skip(P, intensities, labels, preds, dev)
-        rc = _lib.lib().mrirt_render_brats_skip(C.byref(P), C.byref(E), vp, _ptr(lab), _ptr(prd), C.byref(S), _ptr(o),
-                                                pitch, _ptr(st), _stream_ptr(stream))
-        _lib.check(rc, "mrirt_render_brats_skip")
-    else:
-        rc = _lib.lib().mrirt_render_brats_ex(C.byref(P), C.byref(E), vp, _ptr(lab), _ptr(prd), _ptr(o),
-                                              pitch, _ptr(st), _stream_ptr(stream))
-        _lib.check(rc, "mrirt_render_brats_ex")
-    if stats:
-        s = st.cpu()
-        return o, {"live_samples": int(s[0]), "shaded_samples": int(s[1])}
+    # every temporary of this call (uploads of host arrays, the output, the counters, the skip mask) is made on
+    # the launch stream, so the kernels are ordered after their producers and the caching allocator ties the
+    # memory to that stream
+    with _on_stream(stream):
+        P, E, vols, lab, prd = _bind_brats(params, intensities, labels, preds, ext, dev)
+        o, pitch = _alloc_out(int(P.imageSize[0]), int(P.imageSize[1]), E, dev, out)
+        vp = (C.c_void_p * 4)(*[C.c_void_p(t.data_ptr()) if t is not None else None for t in vols])
+        st = torch.zeros(2, dtype=torch.int64, device=dev) if stats else None
+        if skip:
+            S, keep = _bind_skip(P, intensities, labels, preds, dev)
+            rc = _lib.lib().mrirt_render_brats_skip(C.byref(P), C.byref(E), vp, _ptr(lab), _ptr(prd), C.byref(S), _ptr(o),
+                                                    pitch, _ptr(st), _stream_ptr(stream))
+            _lib.check(rc, "mrirt_render_brats_skip")
+            del keep
+        else:
+            rc = _lib.lib().mrirt_render_brats_ex(C.byref(P), C.byref(E), vp, _ptr(lab), _ptr(prd), _ptr(o),
+                                                  pitch, _ptr(st), _stream_ptr(stream))
+            _lib.check(rc, "mrirt_render_brats_ex")
+        if stats:
+            s = st.cpu()
+            return o, {"live_samples": int(s[0]), "shaded_samples": int(s[1])}
     return o
 
 
@@ -310,17 +327,18 @@ def render_volume_u8(params: Mapping[str, Any], volume: ArrayLike, mode: str = "
         t = t.to(torch.int64).to(torch.int32)
     if t.dtype != dt:
         raise TypeError(f"gVolumeU8 ({mode}): expected {dt}, got {t.dtype}")
-    t = t.to(dev).contiguous().reshape(-1)
-    nvox = int(P.volDim[0]) * int(P.volDim[1]) * int(P.volDim[2])
-    if t.numel() < nvox:
-        raise ValueError(f"gVolumeU8 holds {t.numel()} < {nvox} voxels")
-    o, pitch = _alloc_out(int(P.imageSize[0]), int(P.imageSize[1]), E, dev, out)
-    st = torch.zeros(2, dtype=torch.int64, device=dev) if stats else None
-    rc = _lib.lib().mrirt_render_volume(C.byref(P), C.byref(E), _ptr(t), code, _ptr(o), pitch, _ptr(st),
-                                        _stream_ptr(stream))
-    _lib.check(rc, "mrirt_render_volume")
-    if stats:
-        return o, {"live_samples": int(st.cpu()[0])}
+    with _on_stream(stream):                               # uploads and temporaries on the launch stream
+        t = t.to(dev).contiguous().reshape(-1)
+        nvox = int(P.volDim[0]) * int(P.volDim[1]) * int(P.volDim[2])
+        if t.numel() < nvox:
+            raise ValueError(f"gVolumeU8 holds {t.numel()} < {nvox} voxels")
+        o, pitch = _alloc_out(int(P.imageSize[0]), int(P.imageSize[1]), E, dev, out)
+        st = torch.zeros(2, dtype=torch.int64, device=dev) if stats else None
+        rc = _lib.lib().mrirt_render_volume(C.byref(P), C.byref(E), _ptr(t), code, _ptr(o), pitch, _ptr(st),
+                                            _stream_ptr(stream))
+        _lib.check(rc, "mrirt_render_volume")
+        if stats:
+            return o, {"live_samples": int(st.cpu()[0])}
     return o
 
 

@@ -75,11 +75,13 @@ def gather_frame(local_tiles: torch.Tensor, width: int, height: int, tile: int =
         buf = send.new_empty((world * send.shape[0],) + tuple(send.shape[1:]))
         dist.all_gather_into_tensor(buf, send, group=group)
         return assemble_frame(buf.view((world,) + tuple(send.shape)), width, height, tile, world)
+    # ``dst`` is a rank OF THE GROUP (like ``rank`` above); torch's collectives take the global rank
+    gdst = dist.get_global_rank(group, dst) if group is not None else dst
     if rank == dst:
         buf = send.new_empty((world,) + tuple(send.shape))
-        dist.gather(send, list(buf.unbind(0)), dst=dst, group=group)
+        dist.gather(send, list(buf.unbind(0)), dst=gdst, group=group)
         return assemble_frame(buf, width, height, tile, world)
-    dist.gather(send, None, dst=dst, group=group)
+    dist.gather(send, None, dst=gdst, group=group)
     return None
 
 

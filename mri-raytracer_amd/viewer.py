@@ -130,8 +130,12 @@ class BraTSViewer:
         self.camera.target = (self.vol_min + 0.5 * ext).astype(np.float32)
         self.camera.radius = float(np.linalg.norm(ext) * 0.8)
 
-    def load_inr(self, npz_path, config_override=None) -> None:
-        """on_click_load_inr: prepass the whole volume through the MLP and show it as gPreds."""
+    def load_inr(self, npz_path, config_override=None, allow_pickle: bool = False) -> None:
+        """on_click_load_inr: prepass the whole volume through the MLP and show it as gPreds.  The reference's
+        final checkpoints (train.py:386-389) pickle the parameter list; ``allow_pickle=True`` opts in to
+        unpickling for a file the caller trusts (the periodic ``W_i``/``b_i`` checkpoints need no pickle)."""
+        if allow_pickle:
+            config_override = {**(config_override or {}), "ALLOW_PICKLE": True}
         params, config_raw = inr_model.model_load(npz_path, config_override)
         cfg = config_raw.get("config", config_raw)
         k = int(cfg.get("FOURIER_FREQS", cfg.get("fourier_freqs", 10)))

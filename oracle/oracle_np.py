@@ -838,17 +838,17 @@ def model_load(npz_path, config_override=None):
     as written by inr/inr/train.py:216-223)."""
     npz_path = pathlib.Path(npz_path).expanduser().resolve()
     if not npz_path.is_file():
-        raise FileNotFoundError(f"NPZ file not found: {npz_path}")
+        raise FileNotFoundError(f"no checkpoint archive at {npz_path}")
     cfg_path = npz_path.with_name(f"{npz_path.stem}_info.json")
     if not cfg_path.is_file():
-        raise FileNotFoundError(f"Config JSON not found next to NPZ: {cfg_path}")
+        raise FileNotFoundError(f"sidecar {cfg_path.name} is missing beside {npz_path.name}")
     with np.load(str(npz_path), allow_pickle=False) as z:
         names = list(z.files)
         if all(k[:2] in ("W_", "b_") for k in names) and names:
             n = len([k for k in names if k.startswith("W_")])
             params = [{"W": z[f"W_{i}"], "b": z[f"b_{i}"]} for i in range(n)]
         else:
-            raise KeyError(f"Could not find 'params' key in {npz_path}; available keys: {names}")
+            raise KeyError(f"{npz_path} has no W_i/b_i arrays (entries: {names})")
     config = json.loads(cfg_path.read_text())
     if config_override is not None:
         config = {**config, **config_override}

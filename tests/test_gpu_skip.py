@@ -32,7 +32,8 @@ def mask_fraction(dims):
     d = (C.c_uint32 * 3)(*dims)
     cells = int(_lib.lib().mrirt_macro_cells(d))
     words = int(_lib.lib().mrirt_skip_mask_words(d))
-    m = render._MASKS[(torch.cuda.current_device(), words)].cpu().numpy().view(np.uint32)
+    assert render._last_skip_mask.numel() == words
+    m = render._last_skip_mask.cpu().numpy().view(np.uint32)
     bits = np.unpackbits(m.view(np.uint8), bitorder="little")[:cells]
     return float(bits.mean())
 

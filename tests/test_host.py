@@ -206,3 +206,37 @@ def test_torch_ops_are_registered_with_shape_functions():
     assert o.shape == (10, 4)
     with pytest.raises(TypeError):
         torch.ops.mrirt.render_brats(blob[:-4], ext, v, None, None, None, None, None)
+
+
+def test_bad_steps_are_refused_on_the_host_not_hung_on_the_gpu():
+    """a step that is <= 0, NaN or too small to advance t in fp32 would spin the march loop
+    (`while (t < t1 && T > ert) ... t += stepSize`, and the C5 count/emit loops have no transmittance exit).
+    prepare() refuses those with MRIRT_ERR_ARG before anything is launched — checked here without a GPU by
+    passing non-NULL dummy pointers that are never dereferenced on an error return."""
+    lib = _lib.lib()
+    good = synth.brats_scene(32, 64, 64, channels=1)
+    dummy = C.c_void_p(0x1000)
+    vp = (C.c_void_p * 4)(dummy, None, None, None)
+
+    def rc_ex(p):
+        P = params.brats_params(p)
+        return lib.mrirt_render_brats_ex(C.byref(P), None, vp, None, None, dummy, 64, None, None)
+
+    for bad in (0.0, -0.01, float("nan"), float("inf"), 1e-9, 1.8 * 3 ** 0.5 / (1 << 21)):
+        assert rc_ex(dict(good, stepSize=bad)) == -5, bad
+    far = dict(good, eye=np.asarray(good["eye"]) * 1e6)          # t ~ 3e6: a 0.01 step no longer moves it
+    assert rc_ex(dict(far, stepSize=0.01)) == -5
+    assert rc_ex(dict(good, voxelSize=(0.0, 0.01, 0.01))) == -5
+    assert rc_ex(dict(good, voxelSize=(float("nan"), 0.01, 0.01))) == -5
+    # the same gate guards the C5 passes
+    P = params.brats_params(dict(good, stepSize=0.0))
+    assert lib.mrirt_brats_sample_counts(C.byref(P), None, dummy, None) == -5
+    assert b"argument" in lib.mrirt_status_string(-5).lower() or b"arg" in lib.mrirt_status_string(-5).lower()
+    # K2: the loop count is uint(max(1, stepCount)); K3: maxSteps
+    V = params.volume_params(synth.volume_scene(16, 32, 64))
+    for bad in (float("nan"), float("inf"), 3e9):
+        V.stepCount = bad
+        assert lib.mrirt_render_volume(C.byref(V), None, dummy, 1, dummy, 32, None, None) == -5
+    sp, eye, U, Vv, W = synth.sdf_scene()
+    S = params.sdf_params(dict(sp, maxSteps=np.uint32(1 << 24)), eye, U, Vv, W)
+    assert lib.mrirt_render_sdf(C.byref(S), 32, 32, dummy, 32, None) == -5

@@ -190,3 +190,68 @@ def test_markstein_division_by_255_is_exact_for_every_byte():
     assert np.array_equal(e.astype(np.float32).astype(np.float64), e)   # ... and it is representable
     got = (e * np.float64(r) + q.astype(np.float64)).astype(np.float32)
     assert np.array_equal(got, x / np.float32(255.0))
+
+
+# ---------------------------------------------------------------------------------------------------
+# Third-party cross-check: the K1/K2/K3 oracle cannot be pinned by anything the reference
+# holds (no tests, no golden images, Slang not runnable here), so the only INDEPENDENT implementation of the
+# same semantics available is torch's `grid_sample` (5-D input = trilinear; align_corners=True; border
+# padding — SURVEY.md 8d item 3).  It interpolates in a different operation order, so the comparison is to a
+# tolerance, not to the bit; it does not turn "parity unpinned" green, it bounds how wrong the restatement of
+# sampleLinear (brats_rt.slang:60-76) and of the march (:117-141) could be.
+# ---------------------------------------------------------------------------------------------------
+def _grid_sample(vol_zyx, q_xyz):
+    import torch
+    import torch.nn.functional as F
+    Z, Y, X = vol_zyx.shape
+    dims = torch.tensor([X, Y, Z], dtype=torch.float64)
+    g = 2.0 * torch.from_numpy(q_xyz.astype(np.float64)) / (dims - 1.0) - 1.0
+    out = F.grid_sample(torch.from_numpy(vol_zyx.astype(np.float64))[None, None], g[None, None, None],
+                        mode="bilinear", padding_mode="border", align_corners=True)
+    return out[0, 0, 0, 0].numpy()
+
+
+def test_sample_linear_agrees_with_torch_grid_sample():
+    rng = np.random.default_rng(21)
+    X, Y, Z = 19, 14, 11
+    vol = rng.random((Z, Y, X), dtype=np.float32)
+    lin = vol.reshape(-1)
+    n = 20000
+    q = (rng.random((n, 3)) * (np.array([X, Y, Z]) - 1.001)).astype(np.float32)        # pIdx in [0, N - 1.001]
+    q[:64] = np.floor(q[:64])                                                           # lattice points
+    q[64:96, 0] = np.float32(X - 1.001)                                                 # the clamp's upper edge
+    want = _grid_sample(vol, q)
+    got = onp._sample_linear(lin, q[:, 0], q[:, 1], q[:, 2], X, Y, Z)[0]
+    assert got.dtype == np.float32
+    assert np.abs(got - want).max() <= 4e-7, np.abs(got - want).max()                   # a few fp32 ulps of values in [0,1]
+    assert np.array_equal(got[:64], lin[(q[:64, 0] + q[:64, 1] * X + q[:64, 2] * X * Y).astype(np.int64)])
+    # outside the box the shader clamps (brats_rt.slang:62-64); border padding does the same below 0
+    qo = q.copy()
+    qo[:, 1] -= np.float32(30.0)
+    qc = qo.copy()
+    qc[:, 1] = 0.0
+    assert np.abs(onp._sample_linear(lin, qo[:, 0], qo[:, 1], qo[:, 2], X, Y, Z)[0] - _grid_sample(vol, qc)).max() <= 4e-7
+
+
+def test_k1_frame_agrees_with_an_independent_torch_march():
+    """One K1 frame (one modality, ERT, dense preset) marched by tools/cpu_torch_baseline.py's grid_sample
+    renderer — different code, different interpolation order, fp32 torch ops — within the BASELINE's 1e-4."""
+    import importlib.util
+    import pathlib
+    import torch
+    spec = importlib.util.spec_from_file_location(
+        "cpu_torch_baseline", pathlib.Path(__file__).resolve().parent.parent / "tools" / "cpu_torch_baseline.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    synth, p = _scene(n=40, image=72, steps=96, channels=1, intensity_alpha=16.0)
+    vol = synth.synth_volume(40)
+    with torch.no_grad():
+        img, live = mod.render(p, vol, 40)
+    ref, aux = onp.brats_main(p, [vol], return_aux=True)
+    assert np.array_equal(ref, oracle_c.brats_main(p, [vol]))
+    d = np.abs(img.numpy() - ref[..., 0])
+    # knife-edge pixels (a ray whose T lands within rounding of 0.01, or whose last step lands on t1) may take
+    # one step more or fewer in the other implementation: bounded by one step's contribution
+    assert np.quantile(d, 0.999) <= 1e-4, np.quantile(d, 0.999)
+    assert d.max() <= 0.011
+    assert abs(live - int(aux["nsteps"].sum())) <= 0.002 * live
