@@ -1,22 +1,30 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark of the MI355X-native MRI ray-marcher.
 
-Metric (BASELINE.json): Msamples/s and achieved HBM GB/s, 512^3 fp32 volume @ 1024^2 x 512
-steps.  The N=1 workload is BASELINE config 3 ("C3"): one fp32 channel, perspective rays,
-central-difference gradient + Blinn-Phong shading, early-ray termination (T <= 0.01), on the
-synthetic scene of SURVEY.md section 8(d) (``mrirt.synth``; intensityAlpha 16 so that
-termination fires).  A *step* is one rendered frame: ray generation, march, composite and the
-framebuffer store — and, for N > 1, the RCCL all-gather of the tiles plus de-tiling on rank 0
-(issued asynchronously: frame k's exchange overlaps frame k+1's march; all K frames are fully
-exchanged and de-tiled before the clock stops).
+Metric (BASELINE.json): Msamples/s and achieved HBM GB/s, 512^3 fp32 volume @ 1024^2 x 512 steps.
 
-``value`` = live samples of all ranks' frames / wall time.  Live samples (march-loop iterations
-that fetch the volume) are counted by the kernel itself in an untimed pass, so skipping work
-cannot inflate the rate.  Inputs are resident in HBM before the timed region.
+N = 1: BASELINE config 3 ("C3") — one fp32 channel, perspective rays, central-difference gradient +
+Blinn-Phong shading, early-ray termination (T <= 0.01), 1024 x 1024 px, on the synthetic scene of SURVEY.md
+section 8(d) (``mrirt.synth``; intensityAlpha 16 so that termination fires).
+N > 1 (launched by torch.distributed.run, one rank per GPU): BASELINE config 4 ("C4") — the same kernel and
+volume at a FIXED 2048 x 2048 image (strong scaling): 64 x 64 tiles dealt round-robin to the ranks, volume
+replicated, one RCCL gather of the compact tile buffers to rank 0 per frame (each peer's 1/N of the frame crosses
+its own xGMI link to the root once), de-tiling kernel on rank 0.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling — the image grows to
-about N x 1024^2 pixels (side 1024*sqrt(N) rounded to the tile size), 64x64 tiles dealt
-round-robin to ranks, volume replicated, one gather per frame.
+A *step* is one rendered frame: ray generation, march, composite and the framebuffer store — and, for N > 1,
+the gather plus de-tiling (issued asynchronously: frame k's exchange overlaps frame k+1's march; all K frames
+are fully exchanged and de-tiled before the clock stops).
+
+``value`` = live samples of all ranks' frames / wall time.  Live samples (march-loop iterations that fetch the
+volume) are counted by the kernel itself in an untimed pass, so skipping work cannot inflate the rate.  Inputs
+are resident in HBM before the timed region.
+
+``roofline`` (dominant kernel, this rank's launch): ``frac`` = HBM bytes per launch / kernel time / 8 TB/s, where
+the bytes are the rocprofv3 PMC measurement committed in profiles/traffic.json — used only while the kernel
+sources still have the digest they were measured on (tools/srchash.py); otherwise ``traffic`` is null and the
+fraction falls back to the COMPULSORY bytes (volume once + framebuffer), a floor of the real traffic, and says
+so in ``basis``.  SURVEY 8(d)'s algorithmic rate (cache-served taps, can exceed the HBM peak) is kept as
+``algorithmic_GBs``; ``on_chip`` carries the two on-chip roofs that actually bind this kernel.
 
 Prints ONE JSON line (rank 0).
 """
@@ -47,7 +55,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--volume", type=int, default=512, help="volume side N (N^3 fp32)")
-    ap.add_argument("--image", type=int, default=0, help="image side; 0 = 1024*sqrt(gpus) rounded to the tile")
+    ap.add_argument("--image", type=int, default=0, help="image side; 0 = 1024 at one GPU (C3), 2048 at N > 1 (C4)")
     ap.add_argument("--march-steps", type=int, default=512)
     ap.add_argument("--math", default="strict", choices=["strict", "fast"])
     ap.add_argument("--layout", default="auto", choices=["auto", "vg", "quad", "brick", "linear"],
@@ -61,19 +69,25 @@ def parse():
     ap.add_argument("--no-inr", action="store_true", help="skip the INR (MFMA) side measurement")
     ap.add_argument("--force-exchange", action="store_true",
                     help="N=1 only: still create the RCCL group (world size 1), render compact tiles and run the "
-                         "asynchronous all-gather + de-tiling path — a single-GPU rehearsal of the N>1 code")
+                         "asynchronous gather + de-tiling path — a single-GPU rehearsal of the N>1 code")
     return ap.parse_args()
 
 
 def measured_traffic(key):
-    """(HBM bytes per launch, on-chip utilisation figures) from the committed rocprofv3 PMC passes
-    (profiles/traffic.json), or (None, None) when this configuration has not been profiled."""
+    """(HBM bytes per launch, on-chip utilisation figures, note) from the committed rocprofv3 PMC passes
+    (profiles/traffic.json) — only when the entry was measured on the kernel sources this tree holds."""
     try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import srchash
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
             entry = json.load(fh).get(key)
-        return (int(entry["hbm_bytes_per_launch"]), entry.get("on_chip")) if entry else (None, None)
-    except (OSError, ValueError, KeyError):
-        return None, None
+        if not entry:
+            return None, None, "no PMC entry for this configuration"
+        if entry.get("source_digest") != srchash.source_digest():
+            return None, None, "PMC entry is stale: measured on other kernel sources (tools/srchash.py digest differs)"
+        return int(entry["hbm_bytes_per_launch"]), entry.get("on_chip"), entry.get("source")
+    except (OSError, ValueError, KeyError, ImportError) as e:
+        return None, None, f"traffic.json unreadable: {type(e).__name__}"
 
 
 def inr_path(dev):
@@ -173,7 +187,8 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     n = a.volume
-    image = a.image or int(round(1024 * math.sqrt(world) / a.tile)) * a.tile
+    image = a.image or (1024 if world == 1 else 2048)            # C3 at one GPU, C4 (fixed image: strong scaling) beyond
+    cfg_name = {1024: "C3", 2048: "C4"}.get(image, "C3-like") if not a.no_shade else "K1-reference"
     vol = synth.synth_volume(n)                                   # host, deterministic
     params = synth.brats_scene(n, image, a.march_steps, channels=1, intensity_alpha=a.alpha)
     if a.layout == "auto":
@@ -185,7 +200,7 @@ def main():
 
     if grouped:
         my_ext = tiles.shard_ext(ext, rank, world, a.tile)
-        # double-buffered asynchronous exchange: frame k's all-gather overlaps frame k+1's march
+        # double-buffered asynchronous exchange: frame k's gather to rank 0 overlaps frame k+1's march
         ex = tiles.FrameExchange(image, image, a.tile, torch.float32, dev, depth=2, dst=0)
         local = ex.local(0)
     else:
@@ -214,8 +229,10 @@ def main():
     # untimed: sample accounting by the kernel's own counters
     _, st = mrirt.render_brats(params, [grid], out=local, ext=my_ext, stats=True)
     counts = torch.tensor([st["live_samples"], st["shaded_samples"]], dtype=torch.int64, device=dev)
+    per_rank = [counts.clone() for _ in range(world)]
     if world > 1:
-        dist.all_reduce(counts)
+        dist.all_gather(per_rank, counts)
+        counts = torch.stack(per_rank).sum(0)
     live, shaded = int(counts[0]), int(counts[1])
 
     run_frames(a.warmup)
@@ -239,28 +256,56 @@ def main():
         dist.all_reduce(e, op=dist.ReduceOp.MAX)
         elapsed = float(e[0])
     kernel_ms = float(np.mean([s.elapsed_time(t) for s, t in ev]))
+    kernel_ms_all = [kernel_ms]
+    if world > 1:
+        km = torch.tensor([kernel_ms], dtype=torch.float64, device=dev)
+        kms = [km.clone() for _ in range(world)]
+        dist.all_gather(kms, km)
+        kernel_ms_all = [float(k[0]) for k in kms]
+
+    # untimed, after the clock has stopped: the exchange step by itself (gather of one frame's tiles to rank 0
+    # + de-tiling), serialised — what a frame would pay if nothing overlapped it
+    exchange = None
+    if grouped:
+        reps = 5
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            ex.submit(0)
+            ex.finish(0)
+            torch.cuda.synchronize()
+        dist.barrier()
+        ex_ms = (time.perf_counter() - t1) / reps * 1e3
+        exchange = {"collective": "gather to rank 0 (RCCL, torch.distributed) + de-tiling kernel",
+                    "bytes_to_root_per_frame": int((world - 1) * ex.max_local * a.tile * a.tile * 16),
+                    "serial_ms_per_frame": round(ex_ms, 4),
+                    "note": "in the timed loop this step is asynchronous: frame k's gather overlaps frame k+1's march"}
 
     if rank == 0:
         value = live * a.steps / elapsed / 1e6
-        # roofline of the dominant kernel (brats_march_kernel) on THIS rank's launch
+        # roofline of the dominant kernel on THIS rank's launch
         my_live, my_shaded = st["live_samples"], st["shaded_samples"]
         px = local.numel() // 4
         alg_bytes = my_live * BYTES_PER_SAMPLE + my_shaded * BYTES_PER_SHADED + px * BYTES_PER_PIXEL
-        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-        profiled = world == 1 and a.variant == 0 and a.alpha == 16.0
-        traffic, on_chip = measured_traffic(
-            f"{'C3' if not a.no_shade else 'K1'}:{n}:{image}:{a.march_steps}:{a.layout}:{a.math}:"
-            f"{'shade' if not a.no_shade else 'plain'}") if profiled else (None, None)
+        compulsory = grid.nbytes + px * BYTES_PER_PIXEL            # the volume once + this rank's framebuffer
+        profiled = world == 1 and a.variant == 0 and a.alpha == 16.0 and not a.force_exchange
+        key = (f"{'C3' if not a.no_shade else 'K1'}:{n}:{image}:{a.march_steps}:{a.layout}:{a.math}:"
+               f"{'shade' if not a.no_shade else 'plain'}")
+        traffic, on_chip, note = measured_traffic(key) if profiled else (None, None, "not a profiled configuration")
+        hbm_bytes = traffic if traffic is not None else compulsory
+        achieved = hbm_bytes / (kernel_ms * 1e-3) / 1e9
         out = {
-            "metric": "live Msamples/s, 512^3 fp32 volume @ 1024^2 x 512 steps (gradient shading + ERT)",
+            "metric": "live Msamples/s, 512^3 fp32 volume @ 1024^2 x 512 steps (gradient shading + ERT)"
+                      + ("" if image == 1024 else f" [this run: {image}^2]"),
             "value": round(value, 1), "unit": "Msamples/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("C3" if not a.no_shade else "K1-reference") +
+            "config": {"workload": cfg_name +
                        f": {n}^3 fp32 volume, {image}x{image} px, {a.march_steps} steps/ray, perspective, "
-                       + ("central-difference gradient + Blinn-Phong + " if not a.no_shade else "") + "ERT",
+                       + ("central-difference gradient + Blinn-Phong + " if not a.no_shade else "") + "ERT"
+                       + ("" if world == 1 else f"; image fixed as N grows, tiles over {world} ranks"),
                        "math": a.math, "layout": a.layout, "intensityAlpha": a.alpha,
                        "tiles": f"{a.tile}x{a.tile} round-robin over {world} rank(s)",
                        "live_samples_per_frame": live, "shaded_samples_per_frame": shaded,
@@ -270,14 +315,20 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic,
-                         # what actually binds the kernel (PMC passes, profiles/traffic.json): its gathers are
-                         # served by L1/L2, so the HBM fraction above exceeds 1 and says little by itself
+                         "basis": ("rocprofv3 PMC HBM bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE), " + str(note)) if traffic is not None
+                                  else ("compulsory bytes (volume once + framebuffer): a floor of the real traffic; " + str(note)),
+                         # what actually binds the kernel (PMC passes): its gathers are served by L1/L2
                          "on_chip": on_chip,
                          "kernel": "brats_march_pipe_kernel" if not a.variant & 4 else "brats_march_kernel", "kernel_ms": round(kernel_ms, 4),
+                         # SURVEY 8(d)'s accounting: bytes the taps ask for, mostly served by the caches (can exceed the HBM peak)
+                         "algorithmic_GBs": round(alg_bytes / (kernel_ms * 1e-3) / 1e9, 1),
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "compulsory_bytes_per_launch": grid.nbytes + px * BYTES_PER_PIXEL,   # volume once + framebuffer
+                         "compulsory_bytes_per_launch": compulsory,
                          "bytes_per_sample": BYTES_PER_SAMPLE + (0 if a.no_shade else BYTES_PER_SHADED)},
         }
+        if world > 1 or a.force_exchange:
+            out["per_rank"] = {"live_samples": [int(c[0]) for c in per_rank], "march_kernel_ms": [round(k, 4) for k in kernel_ms_all]}
+            out["exchange"] = exchange
         if world == 1 and not a.no_inr:
             out["inr_path"] = inr_path(dev)
         if not a.no_cpu_baseline and a.cpu_rows != 0 and world == 1:

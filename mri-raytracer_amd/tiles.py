@@ -5,7 +5,7 @@ Rays are independent, nothing is reduced: the W x H image is cut into ``tile`` x
 tiles dealt round-robin (tile id mod world size) so early-terminating and empty regions spread
 evenly; the volume is replicated on every GPU (512 MiB for a 512^3 fp32 grid against 288 GB);
 each rank renders its tiles into a compact [n_local, tile, tile, 4] buffer and ONE collective
-moves them: an RCCL gather to rank 0 (``torch.distributed`` backend "nccl" is RCCL on ROCm;
+moves them: an RCCL gather to the root rank (``torch.distributed`` backend "nccl" is RCCL on ROCm;
 each peer's 1/N of the frame crosses its own direct xGMI link to the root), followed by a
 de-tiling copy kernel.  With the gloo backend (CPU tests) the same code path runs on host
 tensors.
@@ -89,11 +89,16 @@ class FrameExchange:
     """Double-buffered, asynchronous form of the exchange step for a frame loop.
 
     ``local(i)`` is the compact tile buffer the march kernel writes for frame slot i (a view of a
-    buffer padded to rank 0's tile count); ``submit(i)`` starts the all-gather of that slot (the
+    buffer padded to rank 0's tile count); ``submit(i)`` starts the exchange of that slot (the
     collective runs on the backend's own stream and waits for the march kernel through stream
     ordering, so the NEXT frame's march overlaps it); ``finish(i)`` waits for it and returns the
-    de-tiled frame (on ``dst`` only, None elsewhere).  Nothing is reduced, so one all-gather per
-    frame is the whole communication."""
+    de-tiled frame (on ``dst`` only, None elsewhere).  Nothing is reduced, so one collective per
+    frame is the whole communication:
+
+    * ``dst`` = a rank of the group (default 0): a GATHER to that rank — each peer's 1/N of the frame
+      crosses its own direct xGMI link to the root once (C4: 8 MiB per peer); the other
+      ranks receive nothing;
+    * ``dst=None``: every rank needs the frame — an all-gather (N times the bytes on the wire)."""
 
     def __init__(self, width: int, height: int, tile: int, dtype: torch.dtype, device, group=None,
                  depth: int = 2, dst: Optional[int] = 0):
@@ -104,8 +109,13 @@ class FrameExchange:
         self.max_local = local_tile_count(width, height, tile, 0, self.world)
         shape = (self.max_local, tile, tile, 4)
         self._send = [torch.zeros(shape, dtype=dtype, device=device) for _ in range(depth)]
+        self.receives = dst is None or self.rank == dst
+        # only a rank that ends up with the frame holds a receive buffer (N x the send buffer)
         self._recv = [torch.empty((self.world * self.max_local, tile, tile, 4), dtype=dtype, device=device)
-                      for _ in range(depth)]
+                      if self.receives else None for _ in range(depth)]
+        self._gdst = None
+        if dst is not None and dist.is_initialized():
+            self._gdst = dist.get_global_rank(group, dst) if group is not None else dst
         self._work = [None] * depth
 
     def local(self, i: int) -> torch.Tensor:
@@ -115,13 +125,19 @@ class FrameExchange:
         if not dist.is_initialized():                 # single process, no group: nothing to exchange
             self._recv[i].copy_(self._send[i])
             return
-        self._work[i] = dist.all_gather_into_tensor(self._recv[i], self._send[i], group=self.group, async_op=True)
+        if self.dst is None:
+            self._work[i] = dist.all_gather_into_tensor(self._recv[i], self._send[i], group=self.group, async_op=True)
+        elif self.rank == self.dst:
+            parts = list(self._recv[i].view(self.world, self.max_local, self.tile, self.tile, 4).unbind(0))
+            self._work[i] = dist.gather(self._send[i], parts, dst=self._gdst, group=self.group, async_op=True)
+        else:
+            self._work[i] = dist.gather(self._send[i], None, dst=self._gdst, group=self.group, async_op=True)
 
     def finish(self, i: int) -> Optional[torch.Tensor]:
         if self._work[i] is not None:
             self._work[i].wait()          # orders the current stream after the collective
             self._work[i] = None
-        if self.dst is not None and self.rank != self.dst:
+        if not self.receives:
             return None
         g = self._recv[i].view(self.world, self.max_local, self.tile, self.tile, 4)
         return assemble_frame(g, self.w, self.h, self.tile, self.world)
