@@ -90,28 +90,66 @@ def measured_traffic(key):
         return None, None, f"traffic.json unreadable: {type(e).__name__}"
 
 
-def inr_path(dev):
-    """The other half of the north star, measured in the same run: BASELINE config C5's MLP (SIREN 7 -> 4 x 256 -> 4,
-    512^2 x 256 = 67.1 M queries, random weights and inputs resident in HBM) on the bf16 MFMA kernel, against the
-    dense bf16 peak.  HIP events on the launch stream; three untimed launches, five timed."""
+def siren_c5(rng):
+    """The 4 x 256 SIREN of BASELINE config 5 (7 -> 256 x 4 -> 4) with the notebook's initialisation
+    (neumors_inr.ipynb:1150-1163: U(-r, r), r = sqrt(6 / fan_in), / w0 on the first layer)."""
+    dims = [7, 256, 256, 256, 256, 4]
+    params = []
+    for i in range(len(dims) - 1):
+        r = math.sqrt(6.0 / dims[i]) / (30.0 if i == 0 else 1.0)
+        params.append({"W": rng.uniform(-r, r, (dims[i], dims[i + 1])).astype(np.float32),
+                       "b": rng.uniform(-0.05, 0.05, dims[i + 1]).astype(np.float32)})
+    return dims, params
+
+
+def inr_path(dev, frames=5):
+    """The other half of the north star, measured in the same run: BASELINE config 5 AS A FRAME — 256^3 x 4
+    modalities (BraTS-shaped synthetic scene), 512 x 512 px, 256 samples/ray, the prediction overlay's class of
+    every LIVE sample queried from a 4 x 256 SIREN on the bf16 MFMA kernel (mrirt_render_brats_inr: ERT-aware
+    passes of 32 steps: plan + emit -> MLP -> composite).  HIP events around whole frames on the launch stream.
+    ``roofline`` prices the frame: useful flops = live (composited) samples x flop/query over the frame time.
+    ``mlp_kernel`` is the MLP kernel by itself on 67.1 M resident random queries (512^2 x 256 nominal)."""
     import ctypes as C
     import torch
     import mrirt
-    from mrirt import _lib, inr
-    n = 512 * 512 * 256
-    dims = [7, 256, 256, 256, 256, 4]
+    from mrirt import _lib, inr, synth
     rng = np.random.default_rng(0)
-    params = [{"W": (rng.uniform(-1, 1, (dims[i], dims[i + 1])) * math.sqrt(6 / (dims[i] + dims[i + 1]))).astype(np.float32),
-               "b": rng.uniform(-0.1, 0.1, dims[i + 1]).astype(np.float32)} for i in range(len(dims) - 1)]
+    dims, params = siren_c5(rng)
+    flop = 2 * sum(dims[i] * dims[i + 1] for i in range(len(dims) - 1))
     net = inr.pack_mlp(params, inr.KIND_SIREN, 0, 4)
-    coords = torch.rand((n, 3), device=dev) * 2 - 1
-    feats = torch.rand((n, 4), device=dev)
-    out = torch.empty(n, dtype=torch.int16, device=dev)
+
+    # ---- the frame ---------------------------------------------------------------------------------------
+    n, image, steps = 256, 512, 256
+    vols = [synth.synth_volume(n, 1234 + m, phase=0.3 * m) for m in range(4)]
+    lab = synth.synth_labels(n)
+    zmu = [float(v[v != 0].mean()) for v in vols]
+    zsg = [float(v[v != 0].std() + 1e-6) for v in vols]
+    p5 = synth.brats_scene(n, image, steps, channels=4, show_seg=True, show_pred=True, intensity_alpha=0.4)
+    gv = [mrirt.upload_grid(v, (n, n, n), "quad") for v in vols]
+    gl = mrirt.upload_grid(lab, (n, n, n), "brick")
+    out = torch.empty((image, image, 4), dtype=torch.float32, device=dev)
+    _, aux = inr.render_brats_inr(p5, gv, net, zmu, zsg, labels=gl, out=out, return_aux=True)     # untimed: accounting
+    for _ in range(2):
+        inr.render_brats_inr(p5, gv, net, zmu, zsg, labels=gl, out=out)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(frames)]
+    for e0, e1 in ev:
+        e0.record(); inr.render_brats_inr(p5, gv, net, zmu, zsg, labels=gl, out=out); e1.record()
+    torch.cuda.synchronize()
+    frame_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))
+    live, queries = aux["live_samples"], aux["queries"]
+    tf_frame = flop * live / (frame_ms * 1e-3) / 1e12
+    del gv, gl
+
+    # ---- the MLP kernel alone ----------------------------------------------------------------------------
+    nq = 512 * 512 * 256
+    coords = torch.rand((nq, 3), device=dev) * 2 - 1
+    feats = torch.randn((nq, 4), device=dev)
+    cls = torch.empty(nq, dtype=torch.int16, device=dev)
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     def launch():
         _lib.check(_lib.lib().mrirt_inr_forward(C.byref(net.desc), C.c_void_p(coords.data_ptr()), C.c_void_p(feats.data_ptr()),
-                                                n, None, C.c_void_p(out.data_ptr()), stream), "mrirt_inr_forward")
+                                                nq, None, C.c_void_p(cls.data_ptr()), stream), "mrirt_inr_forward")
     for _ in range(3):
         launch()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
@@ -119,13 +157,20 @@ def inr_path(dev):
         e0.record(); launch(); e1.record()
     torch.cuda.synchronize()
     ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))
-    flop = 2 * sum(dims[i] * dims[i + 1] for i in range(len(dims) - 1))
-    tflops = flop * n / (ms * 1e-3) / 1e12
-    return {"workload": "C5 MLP: SIREN 7->4x256->4, 512^2 x 256 = 67.1 M queries, bf16 MFMA, fp32 accumulate",
-            "value": round(n / (ms * 1e-3) / 1e6, 1), "unit": "Mqueries/s", "ms_per_launch": round(ms, 3), "dtype": "bf16",
-            "roofline": {"bound": "mfma", "achieved": round(tflops, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(tflops / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
-                         "kernel": "inr_forward_kernel", "flop_per_query": flop}}
+    tflops = flop * nq / (ms * 1e-3) / 1e12
+    return {"workload": "C5 frame: 256^3 x 4 modalities + seg, 512x512 px, 256 samples/ray, per-sample SIREN 7->4x256->4 "
+                        "(bf16 MFMA, fp32 accumulate), ERT-aware passes of 32 steps",
+            "value": round(live / (frame_ms * 1e-3) / 1e6, 1), "unit": "M live queries/s", "ms_per_frame": round(frame_ms, 3),
+            "dtype": "bf16", "live_samples_per_frame": live, "mlp_queries_per_frame": queries,
+            "nominal_samples_per_frame": image * image * steps,
+            "roofline": {"bound": "mfma", "achieved": round(tf_frame, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(tf_frame / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                         "basis": "live samples x flop/query over the whole frame time (plan + emit + MLP + composite)",
+                         "flop_per_query": flop},
+            "mlp_kernel": {"workload": "inr_forward_kernel alone: 67.1 M resident random queries", "ms_per_launch": round(ms, 3),
+                           "Mqueries_s": round(nq / (ms * 1e-3) / 1e6, 1),
+                           "roofline": {"bound": "mfma", "achieved": round(tflops, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
+                                        "unit": "TFLOP/s", "frac": round(tflops / MFMA_BF16_PEAK_TFLOPS, 4)}}}
 
 
 def cpu_baseline(params, vol, ext, rows, n_image):

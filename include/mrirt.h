@@ -151,6 +151,8 @@ int mrirt_render_brats_stream(const MrirtBratsParams* params, const MrirtRenderE
                               const int16_t* classes, const int64_t* offsets,
                               void* out_rgba, int64_t pitch_px, uint64_t* stats_dev, void* stream);
 
+/* The one-call, chunked and ERT-aware form of this render is mrirt_render_brats_inr (declared after the INR section). */
+
 /* ------------------------------------------------------------------------------------ */
 /* Brick layout conversion (load-time; replaces create_buffer + copy_from_numpy,         */
 /* inr/viewer/brats_viewer.py:219-230)                                                   */
@@ -283,6 +285,26 @@ int mrirt_inr_forward(const MrirtInrDesc* desc, const float* coords, const float
 /* predict_volume (inr/inr/model.py:119-141): mods[M][H][W][D] fp32 -> pred[H][W][D] int16 */
 int mrirt_inr_predict_volume(const MrirtInrDesc* desc, const float* mods, const uint32_t hwd[3],
                              int16_t* pred, void* stream);
+
+/* ------------------------------------------------------------------------------------ */
+/* Per-sample INR render, one call (BASELINE config 5)                                   */
+/* ------------------------------------------------------------------------------------ */
+/* The same render as ONE call, chunked and ERT-aware (north star: "all LIVE sample points"): the march advances
+ * chunk_steps per pass; each pass emits the MLP inputs of the next <= chunk_steps samples of every ray that is
+ * still alive (t < t1 and T > 0.01 after the previous pass), classifies that batch with the MFMA forward and
+ * composites it, so a ray that has terminated is not classified any further (a ray that terminates inside a pass
+ * wastes at most chunk_steps - 1 queries).  Batch sizes stay in device memory: nothing synchronises with the host.
+ *   net      : Fourier/ReLU (MRIRT_INR_FOURIER_RELU) or SIREN (MRIRT_INR_SIREN, the 7-input network of
+ *              notebooks/neumors_inr.ipynb:853-899,1165-1178: x = (coords, 4 z-scored modalities)), numMods == 4
+ *   scratch  : device memory of mrirt_brats_inr_scratch_bytes(params, chunk_steps) bytes, owned by the caller
+ *   stats_dev: optional, THREE device uint64 counters, atomically incremented by
+ *              {composited (live) samples, gradient-shaded samples, MLP queries}
+ * The frame is bit-identical to mrirt_brats_sample_counts / _emit_samples / mrirt_render_brats_stream run over whole rays (the MLP is batch-position invariant). */
+int64_t mrirt_brats_inr_scratch_bytes(const MrirtBratsParams* params, uint32_t chunk_steps);
+int mrirt_render_brats_inr(const MrirtBratsParams* params, const MrirtRenderExt* ext, const void* const vol[4],
+                           const void* labels, const MrirtInrDesc* net, const float zmu[4], const float zsigma[4],
+                           uint32_t chunk_steps, void* scratch, int64_t scratch_bytes,
+                           void* out_rgba, int64_t pitch_px, uint64_t* stats_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------ */
 /* Misc                                                                                  */

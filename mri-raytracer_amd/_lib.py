@@ -21,7 +21,7 @@ HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-s
 # every extern "C" symbol include/mrirt.h declares
 ABI_SYMBOLS = [
     "mrirt_render_brats", "mrirt_render_brats_ex", "mrirt_brats_sample_counts", "mrirt_brats_emit_samples",
-    "mrirt_render_brats_stream", "mrirt_brick_elems", "mrirt_brick_grid",
+    "mrirt_render_brats_stream", "mrirt_brats_inr_scratch_bytes", "mrirt_render_brats_inr", "mrirt_brick_elems", "mrirt_brick_grid",
     "mrirt_unbrick_grid", "mrirt_vec4_elems", "mrirt_build_vec4_grid", "mrirt_bc4_decode", "mrirt_macro_cells", "mrirt_skip_mask_words",
     "mrirt_build_macro_max", "mrirt_build_macro_labels", "mrirt_render_brats_skip", "mrirt_render_volume", "mrirt_build_cell8", "mrirt_render_sdf", "mrirt_tiles_for_rank",
     "mrirt_detile", "mrirt_inr_pack_bytes", "mrirt_inr_pack_weights", "mrirt_inr_forward",
@@ -158,6 +158,11 @@ def lib() -> C.CDLL:
                                             vp, i64, vp, vp]
     for fn in ("mrirt_brats_sample_counts", "mrirt_brats_emit_samples", "mrirt_render_brats_stream"):
         getattr(l, fn).restype = i32
+    l.mrirt_brats_inr_scratch_bytes.argtypes = [C.POINTER(BratsParams), u32]
+    l.mrirt_brats_inr_scratch_bytes.restype = i64
+    l.mrirt_render_brats_inr.argtypes = [C.POINTER(BratsParams), C.POINTER(RenderExt), C.POINTER(vp), vp, C.POINTER(InrDesc),
+                                         C.POINTER(f32), C.POINTER(f32), u32, vp, i64, vp, i64, vp, vp]
+    l.mrirt_render_brats_inr.restype = i32
     l.mrirt_brick_elems.argtypes = [C.POINTER(u32)]
     l.mrirt_brick_elems.restype = i64
     l.mrirt_brick_grid.argtypes = [vp, vp, C.POINTER(u32), u32, vp]

@@ -554,9 +554,34 @@ struct EmitArgs {
     float4* feats;
 };
 
+// MLP inputs of the sample at index-space cell `s` -> row `row` of coords / feats (shared by the one-pass and
+// the chunked emission)
+template <bool STRICT, int LAYOUT>
+__device__ __forceinline__ void emit_row(const K1Args& a, const EmitArgs& e, const Cell& s, int64_t row) {
+    using Mm = M<STRICT>;
+    float z[4];
+    Taps<LAYOUT, false> taps[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) taps[m].template issue<true>(a.vol[m], a.grid, s);      // all gathers in flight first
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        float v;
+        taps[m].template eval<STRICT>(s, v, nullptr);
+        z[m] = STRICT ? Mm::divu(v - e.zmu[m], e.zsigma[m]) : (v - e.zmu[m]) * e.zsigma[m].r;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {    // fp64, one rounding: predict_volume's coordinate at lattice points
+        // x / (dim - 1) exactly (Markstein: dim - 1 is a small integer, its significand is never all ones)
+        const double x = (double)clampf(s.q[k], 0.0f, a.hiLab[k]);
+        const double q0 = x * e.rdimM1[k];
+        const double q = __builtin_fma(__builtin_fma(-q0, e.dimM1[k], x), e.rdimM1[k], q0);
+        e.coords[row * 3 + k] = (float)(q * 2.0 - 1.0);
+    }
+    e.feats[row] = make_float4(z[0], z[1], z[2], z[3]);
+}
+
 template <bool STRICT, int LAYOUT>
 __global__ __launch_bounds__(256) void emit_samples_kernel(const K1Args a, const EmitArgs e) {
-    using Mm = M<STRICT>;
     uint32_t px, py;
     int64_t oidx;
     if (map_pixel(a.map, px, py, oidx) != 1) return;
@@ -566,26 +591,112 @@ __global__ __launch_bounds__(256) void emit_samples_kernel(const K1Args a, const
     for (float t = t0; t < t1; t += a.stepSize, ++row) {
         Cell s;
         locate<STRICT>(a, ro, rd, t, s);
-        float z[4];
-        Taps<LAYOUT, false> taps[4];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) taps[m].template issue<true>(a.vol[m], a.grid, s);      // all gathers in flight first
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            float v;
-            taps[m].template eval<STRICT>(s, v, nullptr);
-            z[m] = STRICT ? Mm::divu(v - e.zmu[m], e.zsigma[m]) : (v - e.zmu[m]) * e.zsigma[m].r;
-        }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {    // fp64, one rounding: predict_volume's coordinate at lattice points
-            // x / (dim - 1) exactly (Markstein: dim - 1 is a small integer, its significand is never all ones)
-            const double x = (double)clampf(s.q[k], 0.0f, a.hiLab[k]);
-            const double q0 = x * e.rdimM1[k];
-            const double q = __builtin_fma(__builtin_fma(-q0, e.dimM1[k], x), e.rdimM1[k], q0);
-            e.coords[row * 3 + k] = (float)(q * 2.0 - 1.0);
-        }
-        e.feats[row] = make_float4(z[0], z[1], z[2], z[3]);
+        emit_row<STRICT, LAYOUT>(a, e, s, row);
     }
+}
+
+// ---------------------------------------------------------------------------------------
+// C5, chunked and ERT-aware ("all LIVE sample points", north star): the march advances `chunk` steps per pass.
+//   plan:      every ray still alive (t < t1 and T > ert after the previous pass) counts its next <= chunk steps,
+//              takes a row range of the pass's batch (wave scan + one atomic per wave) and emits those samples' MLP
+//              inputs; the batch size stays in device memory (no host round trip);
+//   classify:  mrirt's MFMA forward over that batch (inr_mlp.hip, point count read from the device word);
+//   composite: the same rays march those steps with the class stream, exactly as brats_main does (ERT tested
+//              before every step), and park their state (t, T, C) for the next pass.
+// A ray that terminates inside a pass has at most chunk - 1 samples classified in vain; a ray that is dead
+// costs nothing in later passes.  The frame is the same bits as the one-pass form (the MLP is batch-position
+// invariant), which tests/test_gpu_inr_render.py holds it to.
+// ---------------------------------------------------------------------------------------
+struct C5Ray { float t, T, C0, C1, C2; uint32_t off, cnt, pad; };      // 32 B per pixel
+
+template <bool STRICT, int LAYOUT>
+__global__ __launch_bounds__(256) void c5_plan_kernel(const K1Args a, const EmitArgs e, C5Ray* __restrict__ rays,
+                                                      uint32_t* __restrict__ counter, uint32_t chunk, uint32_t first) {
+    uint32_t px, py;
+    int64_t oidx;
+    const bool mine = map_pixel(a.map, px, py, oidx) == 1;
+    float ro[3] = { 0, 0, 0 }, rd[3] = { 0, 0, 1 }, t0 = 0.0f, t1 = 0.0f;
+    C5Ray r = { 0.0f, 1.0f, a.bg[0], a.bg[1], a.bg[2], 0u, 0u, 0u };
+    const int64_t pix = mine ? (int64_t)py * a.map.width + px : 0;
+    uint32_t cnt = 0;
+    if (mine) {
+        const bool hit = setup_ray(a, px, py, ro, rd, t0, t1);
+        if (first) r.t = t0; else r = rays[pix];
+        if (hit && r.T > a.ert) {
+            float t = r.t;
+            for (; cnt < chunk && t < t1; ++cnt) t += a.stepSize;           // the march's own running sum
+        }
+    }
+    // row range of this ray inside the pass's batch: exclusive scan over the wave + one atomic per wave
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(incl, o);
+        if ((int)lane >= o) incl += v;
+    }
+    const uint32_t total = __shfl(incl, 63);
+    uint32_t base = 0;
+    if (lane == 0 && total != 0) base = atomicAdd(counter, total);
+    base = __shfl(base, 0);
+    if (!mine) return;
+    r.off = base + incl - cnt;
+    r.cnt = cnt;
+    rays[pix] = r;
+    float t = r.t;
+    for (uint32_t k = 0; k < cnt; ++k, t += a.stepSize) {
+        Cell s;
+        locate<STRICT>(a, ro, rd, t, s);
+        emit_row<STRICT, LAYOUT>(a, e, s, (int64_t)r.off + k);
+    }
+}
+
+template <bool STRICT, int LAYOUT, bool SHADE>
+__global__ __launch_bounds__(256) void c5_composite_kernel(const K1Args a, C5Ray* __restrict__ rays,
+                                                           const int16_t* __restrict__ classes) {
+    using Mm = M<STRICT>;
+    uint32_t px, py;
+    int64_t oidx;
+    const int kind = map_pixel(a.map, px, py, oidx);
+    RayState r = { a.bg[0], a.bg[1], a.bg[2], 1.0f, 0u, 0u };
+    if (kind == 1) {
+        const int64_t pix = (int64_t)py * a.map.width + px;
+        C5Ray st = rays[pix];
+        r.C0 = st.C0; r.C1 = st.C1; r.C2 = st.C2; r.T = st.T;
+        if (st.cnt != 0) {
+            float ro[3], rd[3], t0, t1;
+            setup_ray(a, px, py, ro, rd, t0, t1);
+            float t = st.t;
+            // brats_rt.slang:117: `while (t < t1 && T > 0.01)` — t < t1 holds for these cnt steps by construction
+            for (uint32_t k = 0; k < st.cnt && r.T > a.ert; ++k) {
+                Cell s;
+                locate<STRICT>(a, ro, rd, t, s);
+                float v = 0.0f, g[3] = { 0.0f, 0.0f, 0.0f };
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    if (a.enabled[m] != 0) {
+                        Taps<LAYOUT, SHADE> taps;
+                        float sv, gm[3];
+                        taps.template issue<true>(a.vol[m], a.grid, s);
+                        taps.template eval<STRICT>(s, sv, gm);
+                        v = Mm::mad(sv, a.weight[m], v);
+                        if constexpr (SHADE) {
+#pragma unroll
+                            for (int q = 0; q < 3; ++q) g[q] = Mm::mad(gm[q], a.weight[m], g[q]);
+                        }
+                    }
+                }
+                Labels lb;
+                lb.seg = a.showSeg != 0 ? sample_label(a.labels, a.lab, s.q, a.hiLab) : 0u;
+                lb.pred = (uint32_t)(uint16_t)classes[(int64_t)st.off + k];
+                composite<STRICT, SHADE>(a, rd, lb, v, g, r);
+                t += a.stepSize;
+            }
+            st.t = t; st.T = r.T; st.C0 = r.C0; st.C1 = r.C1; st.C2 = r.C2;
+            rays[pix] = st;
+        }
+    }
+    finish(a, kind, oidx, r);      // the frame so far (complete after the last pass); live-sample counters
 }
 
 struct Prepared { uint32_t layout, math; bool shade, pipe; };
@@ -865,4 +976,126 @@ extern "C" int mrirt_brats_emit_samples(const MrirtBratsParams* p, const MrirtRe
     e.offsets = offsets; e.coords = coords; e.feats = reinterpret_cast<float4*>(feats);
     hipStream_t s = static_cast<hipStream_t>(stream);
     return cfg.math == MRIRT_MATH_STRICT ? launch_emit<true>(a, e, cfg.layout, s) : launch_emit<false>(a, e, cfg.layout, s);
+}
+
+// ---------------------------------------------------------------------------------------
+// C5 as one call: the chunked, ERT-aware per-sample INR render (see c5_plan_kernel).  Everything is enqueued on
+// `stream`; batch sizes travel through device memory, so there is no host synchronisation inside the frame.
+// ---------------------------------------------------------------------------------------
+namespace mrirt {
+
+constexpr uint32_t kC5MaxPasses = 1024;
+
+__global__ void c5_sum_kernel(const uint32_t* __restrict__ counters, uint32_t n, uint64_t* __restrict__ queries) {
+    uint64_t s = 0;
+    for (uint32_t i = threadIdx.x; i < n; i += 64) s += counters[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (threadIdx.x == 0) atomicAdd(reinterpret_cast<unsigned long long*>(queries), (unsigned long long)s);
+}
+
+struct C5Scratch { uint32_t* counters; C5Ray* rays; float* coords; float* feats; int16_t* classes; int64_t cap, bytes; };
+
+static int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
+
+static int c5_carve(const MrirtBratsParams* p, uint32_t chunk, void* base, C5Scratch& sc) {
+    if (!p || chunk == 0 || chunk > 4096) return MRIRT_ERR_ARG;
+    const int64_t px = (int64_t)p->imageSize[0] * p->imageSize[1];
+    if (px <= 0) return MRIRT_ERR_DIMS;
+    sc.cap = px * chunk;
+    if (sc.cap >= ((int64_t)1 << 32)) return MRIRT_ERR_ARG;              // 32-bit row offsets per pass
+    char* b = static_cast<char*>(base);
+    int64_t o = 0;
+    sc.counters = reinterpret_cast<uint32_t*>(b + o); o += align256((int64_t)kC5MaxPasses * 4);
+    sc.rays = reinterpret_cast<C5Ray*>(b + o);        o += align256(px * (int64_t)sizeof(C5Ray));
+    sc.coords = reinterpret_cast<float*>(b + o);      o += align256(sc.cap * 12);
+    sc.feats = reinterpret_cast<float*>(b + o);       o += align256(sc.cap * 16);
+    sc.classes = reinterpret_cast<int16_t*>(b + o);   o += align256(sc.cap * 2);
+    sc.bytes = o;
+    return MRIRT_OK;
+}
+
+template <bool STRICT>
+static int c5_launch_plan(const K1Args& a, const EmitArgs& e, uint32_t layout, C5Ray* rays, uint32_t* counter,
+                          uint32_t chunk, uint32_t first, hipStream_t s) {
+    const dim3 grid(a.map.chunk * kXcds), block(a.map.blockPx == 8 ? 64 : 256);
+    switch (layout) {
+        case MRIRT_LAYOUT_LINEAR: hipLaunchKernelGGL((c5_plan_kernel<STRICT, 0>), grid, block, 0, s, a, e, rays, counter, chunk, first); break;
+        case MRIRT_LAYOUT_BRICK:  hipLaunchKernelGGL((c5_plan_kernel<STRICT, 1>), grid, block, 0, s, a, e, rays, counter, chunk, first); break;
+        case MRIRT_LAYOUT_VG:     hipLaunchKernelGGL((c5_plan_kernel<STRICT, 2>), grid, block, 0, s, a, e, rays, counter, chunk, first); break;
+        default:                  hipLaunchKernelGGL((c5_plan_kernel<STRICT, 3>), grid, block, 0, s, a, e, rays, counter, chunk, first); break;
+    }
+    MRIRT_HIP(hipGetLastError());
+    return MRIRT_OK;
+}
+
+template <bool STRICT>
+static int c5_launch_composite(const K1Args& a, uint32_t layout, bool shade, C5Ray* rays, const int16_t* classes, hipStream_t s) {
+    const dim3 grid(a.map.chunk * kXcds), block(a.map.blockPx == 8 ? 64 : 256);
+#define MRIRT_C5C(L, SH) hipLaunchKernelGGL((c5_composite_kernel<STRICT, L, SH>), grid, block, 0, s, a, rays, classes)
+    switch (layout) {
+        case MRIRT_LAYOUT_LINEAR: if (shade) MRIRT_C5C(0, true); else MRIRT_C5C(0, false); break;
+        case MRIRT_LAYOUT_BRICK:  if (shade) MRIRT_C5C(1, true); else MRIRT_C5C(1, false); break;
+        case MRIRT_LAYOUT_VG:     if (shade) MRIRT_C5C(2, true); else MRIRT_C5C(2, false); break;
+        default:                  if (shade) return MRIRT_ERR_LAYOUT; MRIRT_C5C(3, false); break;
+    }
+#undef MRIRT_C5C
+    MRIRT_HIP(hipGetLastError());
+    return MRIRT_OK;
+}
+
+}  // namespace mrirt
+
+extern "C" int64_t mrirt_brats_inr_scratch_bytes(const MrirtBratsParams* p, uint32_t chunk_steps) {
+    C5Scratch sc;
+    return c5_carve(p, chunk_steps, nullptr, sc) == MRIRT_OK ? sc.bytes : 0;
+}
+
+extern "C" int mrirt_render_brats_inr(const MrirtBratsParams* p, const MrirtRenderExt* ext, const void* const vol[4],
+                                      const void* labels, const MrirtInrDesc* net, const float zmu[4], const float zsigma[4],
+                                      uint32_t chunk_steps, void* scratch, int64_t scratch_bytes,
+                                      void* out_rgba, int64_t pitch_px, uint64_t* stats_dev, void* stream) {
+    if (!out_rgba || !scratch || !net || !vol || !zmu || !zsigma) return MRIRT_ERR_NULL;
+    for (int m = 0; m < 4; ++m) if (!vol[m]) return MRIRT_ERR_NULL;           // the MLP reads all four modalities
+    if (ext && ext->tileSize != 0) return MRIRT_ERR_ARG;                      // whole-frame only
+    if ((net->kind != MRIRT_INR_FOURIER_RELU && net->kind != MRIRT_INR_SIREN) || net->numMods != 4) return MRIRT_ERR_ARG;
+    K1Args a;
+    Prepared cfg;
+    int rc = prepare(p, ext, vol, labels, nullptr, true, pitch_px, a, cfg);
+    if (rc != MRIRT_OK) return rc;
+    if (p->showPred == 0) return MRIRT_ERR_ARG;
+    C5Scratch sc;
+    rc = c5_carve(p, chunk_steps, scratch, sc);
+    if (rc != MRIRT_OK) return rc;
+    if (scratch_bytes < sc.bytes) return MRIRT_ERR_ARG;
+    // passes: no ray takes more than diag / stepSize + 2 steps (prepare() has bounded that quotient)
+    double diag2 = 0.0;
+    for (int k = 0; k < 3; ++k) { const double e = (double)p->voxelSize[k] * (double)p->dims[k]; diag2 += e * e; }
+    const uint64_t maxSteps = (uint64_t)(sqrt(diag2) / (double)p->stepSize) + 3;
+    const uint64_t passes = (maxSteps + chunk_steps - 1) / chunk_steps;
+    if (passes > kC5MaxPasses) return MRIRT_ERR_ARG;
+    EmitArgs e;
+    for (int m = 0; m < 4; ++m) { e.zmu[m] = zmu[m]; e.zsigma[m] = make_udiv(zsigma[m]); }
+    for (int k = 0; k < 3; ++k) { e.dimM1[k] = (double)(p->dims[k] - 1); e.rdimM1[k] = 1.0 / e.dimM1[k]; }
+    e.offsets = nullptr; e.coords = sc.coords; e.feats = reinterpret_cast<float4*>(sc.feats);
+    a.out = out_rgba;
+    a.stats = stats_dev;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    MRIRT_HIP(hipMemsetAsync(sc.counters, 0, (size_t)kC5MaxPasses * 4, s));
+    const bool strict = cfg.math == MRIRT_MATH_STRICT;
+    for (uint32_t c = 0; c < (uint32_t)passes; ++c) {
+        rc = strict ? c5_launch_plan<true>(a, e, cfg.layout, sc.rays, sc.counters + c, chunk_steps, c == 0 ? 1u : 0u, s)
+                    : c5_launch_plan<false>(a, e, cfg.layout, sc.rays, sc.counters + c, chunk_steps, c == 0 ? 1u : 0u, s);
+        if (rc != MRIRT_OK) return rc;
+        rc = inr_forward_dev_n(net, sc.coords, sc.feats, sc.cap, sc.counters + c, sc.classes, s);
+        if (rc != MRIRT_OK) return rc;
+        rc = strict ? c5_launch_composite<true>(a, cfg.layout, cfg.shade, sc.rays, sc.classes, s)
+                    : c5_launch_composite<false>(a, cfg.layout, cfg.shade, sc.rays, sc.classes, s);
+        if (rc != MRIRT_OK) return rc;
+    }
+    if (stats_dev != nullptr) {                                               // stats_dev[2] += MLP queries of the frame
+        hipLaunchKernelGGL(c5_sum_kernel, dim3(1), dim3(64), 0, s, sc.counters, (uint32_t)passes, stats_dev + 2);
+        MRIRT_HIP(hipGetLastError());
+    }
+    return MRIRT_OK;
 }

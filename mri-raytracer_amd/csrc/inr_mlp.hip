@@ -143,6 +143,7 @@ struct InrArgs {
     const float* coords;       // [n][3] or nullptr (volume mode / raw-x kinds)
     const float* feats;        // [n][M]  (points mode)  or mods[M][H*W*D] (volume mode)
     int64_t n;
+    const uint32_t* nDev;      // optional: the point count lives on the device (<= n); lets a producer kernel size the batch
     uint32_t volume;           // 1: points are the voxels of an H x W x D grid in ij order
     uint32_t H, W, D;
     float* logits;
@@ -183,6 +184,10 @@ __global__ __launch_bounds__(512) void inr_forward_kernel(const InrArgs a) {
     const float4* ldsBias = reinterpret_cast<const float4*>(ldsAll + kWQ);
     float4* ldsTab = reinterpret_cast<float4*>(ldsAll + kWQ + kBiasQ);
     float* ldsRaw = reinterpret_cast<float*>(ldsAll + kWQ + kBiasQ + kTabQ);
+    // point count: a launch argument, or (C5's chunked render) a device word written by the producer kernel
+    int64_t nPts = a.n;
+    if (a.nDev != nullptr) { const int64_t nd = (int64_t)*a.nDev; nPts = nd < nPts ? nd : nPts; }
+    if (nPts <= 0) return;                               // uniform: nothing was staged, no barrier is pending
     // Feature table (inr/inr/model.py:11-23 order: coords, per axis [sin k=1..K, cos k=1..K], modalities):
     // feature f of a point is  trig == 1 ? sin(2 pi (raw[src] * mult + phase)) : raw[src]  (trig == 2: the bf16
     // remainder raw[src] - bf16(raw[src]) of the augmented split)  with raw = (c0,c1,c2,
@@ -278,7 +283,7 @@ __global__ __launch_bounds__(512) void inr_forward_kernel(const InrArgs a) {
     // Every load below is unconditional and straight-line (clamped index, value masked afterwards): a load
     // inside a per-feature branch makes hipcc wait vmcnt(0) per feature — one memory round trip each.
     auto load_inputs = [&](int64_t pidx) {
-        const int64_t p = pidx < a.n ? pidx : a.n - 1;   // clamp: compute something, store nothing
+        const int64_t p = pidx < nPts ? pidx : nPts - 1; // clamp: compute something, store nothing
         if (a.kind < 2) {
             // lane half 0 stages its point's raw inputs (3 coords + <= 8 modalities + a zero) in LDS ...
             float* raw = ldsRaw + waveS * 32 * kRawStride + r;       // [input][point]: lanes of a half hit 32 banks
@@ -415,7 +420,7 @@ __global__ __launch_bounds__(512) void inr_forward_kernel(const InrArgs a) {
     // Persistent workgroup: batches of 256 points, round-robin.  The weight stream is cyclic — the head
     // chunk stages layer 0's first chunk of the NEXT batch — so after the first batch no DMA latency,
     // workgroup launch or bias staging is exposed.
-    const int64_t nBatches = (a.n + kInrWaves * 32 - 1) / (kInrWaves * 32);
+    const int64_t nBatches = (nPts + kInrWaves * 32 - 1) / (kInrWaves * 32);
     int64_t pendIdx = -1;
     int16_t pendVal = 0;
     for (int64_t batch = blockIdx.x; batch < nBatches; batch += gridDim.x) {
@@ -520,7 +525,7 @@ __global__ __launch_bounds__(512) void inr_forward_kernel(const InrArgs a) {
             if (f + RD < FH) ring[f % RD] = frag_at(buf, f + RD);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (a.logits != nullptr && pidx < a.n) {         // uniform pointer test; not the throughput path
+        if (a.logits != nullptr && pidx < nPts) {         // uniform pointer test; not the throughput path
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const uint32_t cls = (i & 3) + 8 * (i >> 2) + 4 * h;
@@ -544,7 +549,7 @@ __global__ __launch_bounds__(512) void inr_forward_kernel(const InrArgs a) {
         if (ob > best || (ob == best && oc < bestc)) { best = ob; bestc = oc; }
         // stored at the top of the next batch: issued here, the store would still be in flight at the
         // chunk barrier below, whose vmcnt(0) (for the DMA) would then wait out its whole HBM round trip
-        pendIdx = (a.argmax && h == 0 && pidx < a.n) ? pidx : -1;
+        pendIdx = (a.argmax && h == 0 && pidx < nPts) ? pidx : -1;
         pendVal = (int16_t)bestc;
     }
     next_chunk();
@@ -611,9 +616,21 @@ static int fill_args(const MrirtInrDesc* d, InrArgs& a) {
     a.kind = d->kind; a.K = d->fourierFreqs; a.M = d->numMods; a.w0 = d->w0;
     a.wpack = static_cast<const uint4*>(d->weights);
     a.bias = d->biases;
-    a.coords = nullptr; a.feats = nullptr; a.n = 0; a.volume = 0; a.H = a.W = a.D = 1;
+    a.coords = nullptr; a.feats = nullptr; a.n = 0; a.nDev = nullptr; a.volume = 0; a.H = a.W = a.D = 1;
     a.logits = nullptr; a.argmax = nullptr;
     return MRIRT_OK;
+}
+
+// Internal (mrirt_host.h): the forward pass with the point count read from device memory — used by the
+// chunked C5 render (brats_march.hip), whose producer kernel sizes each chunk's batch on the device.
+int inr_forward_dev_n(const MrirtInrDesc* desc, const float* coords, const float* feats, int64_t nMax,
+                      const uint32_t* nDev, int16_t* argmax, hipStream_t s) {
+    InrArgs a;
+    int rc = fill_args(desc, a);
+    if (rc != MRIRT_OK) return rc;
+    if (desc->kind >= 2 || !coords || !feats || !argmax || !nDev) return MRIRT_ERR_ARG;
+    a.coords = coords; a.feats = feats; a.n = nMax; a.nDev = nDev; a.argmax = argmax;
+    return launch_inr(a, s);
 }
 
 }  // namespace mrirt

@@ -135,4 +135,8 @@ inline void fill_label_addr(LabelAddr& a, const uint32_t dims[3], uint32_t layou
     }
 }
 
+// inr_mlp.hip: the MLP forward with the point count in device memory (argmax only)
+int inr_forward_dev_n(const MrirtInrDesc* desc, const float* coords, const float* feats, int64_t nMax,
+                      const uint32_t* nDev, int16_t* argmax, hipStream_t s);
+
 }  // namespace mrirt

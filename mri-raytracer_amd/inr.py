@@ -189,24 +189,33 @@ def predict_volume(params, case_data: Dict[str, Any], fourier_freqs: int, chunk:
     return pred, case_data["seg"]
 
 
+_C5_SCRATCH: dict = {}
+
+
 def render_brats_inr(params, intensities, net: PackedMLP, zmu, zsigma, labels=None, out=None, ext=None,
-                     return_aux: bool = False):
+                     return_aux: bool = False, chunk_steps: int = 32, one_pass: bool = False):
     """BASELINE config 5 (build-defined): K1 with the prediction overlay's label taken
     from the MLP evaluated AT every march sample (normalised sample coordinates + the four
     trilinear-sampled, z-scored modalities) instead of ``sampleLabel(gPreds)``.
 
-    Three device passes around the MFMA kernel (csrc/brats_march.hip, csrc/inr_mlp.hip):
-    count the samples of every ray, emit the MLP inputs of all of them, classify them in one
-    batched ``mrirt_inr_forward``, then composite with the class stream.  ``net`` must be a
-    Fourier/ReLU network over 4 modalities (``pack_mlp(params, KIND_FOURIER_RELU, K, 4)``);
+    ``net`` is a packed network over 4 modalities: the reference's Fourier/ReLU MLP
+    (``pack_mlp(params, KIND_FOURIER_RELU, K, 4)``, inr/inr/model.py:11-50) or the notebook's SIREN
+    (``pack_mlp(params, KIND_SIREN, 0, 4)``: x = (coords, modalities), neumors_inr.ipynb:853-899,1165-1178).
     ``zmu``/``zsigma`` are the per-modality z-score constants (brats_viewer.py:281-287).
+
+    Default: ``mrirt_render_brats_inr`` — the march advances ``chunk_steps`` per pass and only rays that are still
+    alive (t < t1, T > 0.01) have their next samples classified ("all live sample points"); no host
+    synchronisation inside the frame.  ``one_pass=True`` is the three-pass form over whole rays (count every
+    sample in [t0,t1) -> emit -> ONE batched forward -> composite with the class stream); both give the same
+    bits, and ``return_aux`` of the one-pass form exposes the emitted inputs and classes for the layered tests.
     """
     from .render import _alloc_out, _bind_brats
     dev = _require_gpu()
     if int(params["showPred"]) == 0:
         raise ValueError("render_brats_inr draws the prediction overlay: set gParams.showPred")
-    if net.desc.kind != KIND_FOURIER_RELU or net.desc.numMods != 4:
-        raise ValueError("render_brats_inr needs a Fourier/ReLU network over 4 modalities")
+    if net.desc.kind not in (KIND_FOURIER_RELU, KIND_SIREN) or net.desc.numMods != 4:
+        raise ValueError("render_brats_inr needs a Fourier/ReLU or SIREN network over 4 modalities "
+                         "(pack_mlp(params, KIND_FOURIER_RELU, K, 4) / pack_mlp(params, KIND_SIREN, 0, 4))")
     P, E, vols, lab, _ = _bind_brats(params, intensities, labels, None, ext, dev, pred_stream=True)
     if any(v is None for v in vols):
         raise ValueError("the MLP reads all four modalities: bind gIntensity0..3")
@@ -215,6 +224,25 @@ def render_brats_inr(params, intensities, net: PackedMLP, zmu, zsigma, labels=No
     w, h = int(P.imageSize[0]), int(P.imageSize[1])
     lib, s = _lib.lib(), _stream_ptr(None)
     vp = (C.c_void_p * 4)(*[C.c_void_p(t.data_ptr()) for t in vols])
+    mu = (C.c_float * 4)(*[float(np.float32(v)) for v in zmu])
+    sg = (C.c_float * 4)(*[float(np.float32(v)) for v in zsigma])
+    if not one_pass:
+        nbytes = int(lib.mrirt_brats_inr_scratch_bytes(C.byref(P), int(chunk_steps)))
+        if nbytes <= 0:
+            raise ValueError(f"chunk_steps={chunk_steps}: unsupported (1..4096, image x chunk < 2^32 samples per pass)")
+        key = (dev.index, torch.cuda.current_stream().cuda_stream)
+        scratch = _C5_SCRATCH.get(key)                    # one scratch per (device, stream): reused frame to frame
+        if scratch is None or scratch.numel() < nbytes:
+            scratch = _C5_SCRATCH[key] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        o, pitch = _alloc_out(w, h, E, dev, out)
+        st = torch.zeros(3, dtype=torch.int64, device=dev) if return_aux else None
+        _lib.check(lib.mrirt_render_brats_inr(C.byref(P), C.byref(E), vp, _ptr(lab), C.byref(net.desc), mu, sg,
+                                              int(chunk_steps), _ptr(scratch), scratch.numel(), _ptr(o), pitch,
+                                              _ptr(st), s), "mrirt_render_brats_inr")
+        if return_aux:
+            c = st.cpu()
+            return o, dict(live_samples=int(c[0]), shaded_samples=int(c[1]), queries=int(c[2]), chunk_steps=int(chunk_steps))
+        return o
     counts = torch.empty(h * w, dtype=torch.int32, device=dev)
     _lib.check(lib.mrirt_brats_sample_counts(C.byref(P), C.byref(E), _ptr(counts), s), "mrirt_brats_sample_counts")
     ends = torch.cumsum(counts.to(torch.int64), 0)
@@ -223,18 +251,18 @@ def render_brats_inr(params, intensities, net: PackedMLP, zmu, zsigma, labels=No
     coords = torch.empty((max(total, 1), 3), dtype=torch.float32, device=dev)
     feats = torch.empty((max(total, 1), 4), dtype=torch.float32, device=dev)
     classes = torch.zeros(max(total, 1), dtype=torch.int16, device=dev)
-    mu = (C.c_float * 4)(*[float(np.float32(v)) for v in zmu])
-    sg = (C.c_float * 4)(*[float(np.float32(v)) for v in zsigma])
     _lib.check(lib.mrirt_brats_emit_samples(C.byref(P), C.byref(E), vp, mu, sg, _ptr(offsets), _ptr(coords), _ptr(feats), s),
                "mrirt_brats_emit_samples")
     if total:
         _lib.check(lib.mrirt_inr_forward(C.byref(net.desc), _ptr(coords), _ptr(feats), total, None, _ptr(classes), s),
                    "mrirt_inr_forward")
     o, pitch = _alloc_out(w, h, E, dev, out)
+    st = torch.zeros(2, dtype=torch.int64, device=dev) if return_aux else None
     _lib.check(lib.mrirt_render_brats_stream(C.byref(P), C.byref(E), vp, _ptr(lab), _ptr(classes), _ptr(offsets),
-                                             _ptr(o), pitch, None, s), "mrirt_render_brats_stream")
+                                             _ptr(o), pitch, _ptr(st), s), "mrirt_render_brats_stream")
     if return_aux:
-        return o, dict(queries=total, classes=classes, offsets=offsets, coords=coords, feats=feats, counts=counts)
+        return o, dict(queries=total, live_samples=int(st.cpu()[0]), classes=classes, offsets=offsets, coords=coords,
+                       feats=feats, counts=counts)
     return o
 
 

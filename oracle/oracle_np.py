@@ -814,23 +814,34 @@ def inr_sample_inputs(vols, dims, zmu, zsigma, qx, qy, qz):
 
 
 def brats_main_inr(params, vols, mlp_params, fourier_freqs, zmu, zsigma, labels=None, ext=None, *,
-                   class_stream=None, ray_offsets=None, return_aux=False):
+                   class_stream=None, ray_offsets=None, return_aux=False, kind="fourier", w0=30.0, rows=None,
+                   record=None):
     """K1 with the prediction overlay's label taken from an MLP query at every sample instead of
-    sampleLabel(gPreds).  ``showPred`` must be set.  With
-    ``class_stream``/``ray_offsets`` the labels are read from a per-ray stream (class of sample k of
-    pixel p at class_stream[ray_offsets[p] + k]) — used to check the compositing pass against the
-    GPU's own bf16 classes."""
+    sampleLabel(gPreds).  ``showPred`` must be set.  ``kind``: "fourier" = the
+    reference's Fourier/ReLU MLP (inr/inr/model.py:11-50) on build_input(coords, intensities); "siren" = the
+    notebook's SIREN (neumors_inr.ipynb:853-899,1165-1178) on x = (coords, intensities), ``mlp_params`` in its
+    ``{"l0": {"w","b"}, ...}`` layout.  With ``class_stream``/``ray_offsets`` the labels are read from a
+    per-ray stream (class of sample k of pixel p at class_stream[ray_offsets[p] + k]) — used to check the
+    compositing pass against the GPU's own bf16 classes; with ``rows`` the offsets are those of the band's
+    pixels.  ``record(idx, k, coords, feats, classes)`` is called for every batch of samples (tests)."""
     dims = tuple(int(v) for v in params["dims"])
-    Wd = int(params["imageSize"][0])
 
     def source(idx, k, qx, qy, qz):
-        if class_stream is not None:
+        if class_stream is not None and record is None:
             return class_stream[ray_offsets[idx] + k]
         c, f = inr_sample_inputs(vols, dims, zmu, zsigma, qx, qy, qz)
-        return np.argmax(apply_mlp(mlp_params, build_input(c, f, fourier_freqs)), axis=-1)
+        if kind == "siren":
+            logits = siren_apply(mlp_params, np.concatenate([c, f], axis=-1), w0)
+        else:
+            logits = apply_mlp(mlp_params, build_input(c, f, fourier_freqs))
+        cls = np.argmax(logits, axis=-1)
+        if record is not None:
+            record(idx, k, c, f, logits)
+        if class_stream is not None:
+            return class_stream[ray_offsets[idx] + k]
+        return cls
 
-    del Wd
-    return brats_main(params, vols, labels, source, ext, return_aux=return_aux)
+    return brats_main(params, vols, labels, source, ext, return_aux=return_aux, rows=rows)
 
 
 def model_load(npz_path, config_override=None):
