@@ -29,6 +29,7 @@
 // (hi*hi + hi*lo + lo*hi: ~16 mantissa bits).  A ReLU net's first layer (coordinates, sin(pi k c) features,
 // z-scored intensities) and every hidden layer use plain bf16.
 #include <atomic>
+#include <stdlib.h>
 
 #include "mrirt_host.h"
 
@@ -249,6 +250,9 @@ __global__ __launch_bounds__(512) void inr_forward_kernel(const InrArgs a) {
     // with 8 | N the piece is unconditional and the MFMA stream stays one basic block.
     auto stage_piece = [&](uint32_t fragStart, auto nfragC, int dstBuf, int i) {
         if constexpr (RES) return;
+#ifdef MRIRT_EXP_NODMA
+        return;                                          // timing experiment: no weight staging (results are garbage)
+#endif
         constexpr int N = decltype(nfragC)::value;
         const int f = (int)waveS + i * kInrWaves;                    // scalar: the source is s[base] + lane * 16
         if ((N % kInrWaves == 0) ? (i < N / kInrWaves) : (f < N))
@@ -262,6 +266,9 @@ __global__ __launch_bounds__(512) void inr_forward_kernel(const InrArgs a) {
     };
     uint32_t curFrag = a.L.fragOff[0];                   // RES: first fragment of the chunk being read
     auto frag_at = [&](int buf, int f) {
+#ifdef MRIRT_EXP_NOLDSREAD
+        return __builtin_bit_cast(bf16x8, make_uint4(0x3c003c00u + f, 0x3c003c00u, lane, 0x3c003c00u));
+#endif
         if constexpr (RES) return __builtin_bit_cast(bf16x8, ldsAll[(curFrag + f) * 64 + lane]);
         else return __builtin_bit_cast(bf16x8, lds[buf][f * 64 + lane]);
     };
@@ -283,6 +290,10 @@ __global__ __launch_bounds__(512) void inr_forward_kernel(const InrArgs a) {
     // Every load below is unconditional and straight-line (clamped index, value masked afterwards): a load
     // inside a per-feature branch makes hipcc wait vmcnt(0) per feature — one memory round trip each.
     auto load_inputs = [&](int64_t pidx) {
+#ifdef MRIRT_EXP_NOINPUT
+        for (int t = 0; t < KT0; ++t) for (int s2 = 0; s2 < 2; ++s2) for (int j = 0; j < 8; ++j) { xin_hi[t][s2][j] = (__bf16)(float)(pidx & 7); xin_lo[t][s2][j] = (__bf16)0.0f; }
+        return;
+#endif
         const int64_t p = pidx < nPts ? pidx : nPts - 1; // clamp: compute something, store nothing
         if (a.kind < 2) {
             // lane half 0 stages its point's raw inputs (3 coords + <= 8 modalities + a zero) in LDS ...
@@ -384,7 +395,11 @@ __global__ __launch_bounds__(512) void inr_forward_kernel(const InrArgs a) {
             for (int j = 0; j < 8; j += 2) {
                 const int i = 8 * s + j;
                 f32x2 x = { acc[i], acc[i + 1] };
+#ifdef MRIRT_EXP_NOSIN
+                if (siren) { }
+#else
                 if (siren) { x.x = __builtin_amdgcn_sinf(x.x); x.y = __builtin_amdgcn_sinf(x.y); }
+#endif
                 else x = __builtin_elementwise_max(x, (f32x2){ 0.0f, 0.0f });
                 Hn[o][s][j] = (__bf16)x.x;
                 Hn[o][s][j + 1] = (__bf16)x.y;
@@ -399,7 +414,9 @@ __global__ __launch_bounds__(512) void inr_forward_kernel(const InrArgs a) {
 #pragma unroll
         for (int q = 0; q < PER; ++q) {
             const int i = step * PER + q;
+#ifndef MRIRT_EXP_NOSIN
             if (siren) ap[i] = __builtin_amdgcn_sinf(ap[i]);
+#endif
             if (i & 1) {
                 f32x2 x = { ap[i - 1], ap[i] };
                 if (!siren) x = __builtin_elementwise_max(x, (f32x2){ 0.0f, 0.0f });
@@ -412,7 +429,11 @@ __global__ __launch_bounds__(512) void inr_forward_kernel(const InrArgs a) {
     // with vmcnt(0) at the barrier)
     auto next_chunk = [&]() {
         if constexpr (RES) curFrag = nextFrag;           // nothing is staged, nothing to wait for
+#ifdef MRIRT_EXP_NOBARRIER
+        else { buf ^= 1; }
+#else
         else { __syncthreads(); buf ^= 1; }
+#endif
     };
 
     __syncthreads();                                     // biases and layer-0 chunk 0 are in LDS
@@ -559,6 +580,328 @@ __global__ __launch_bounds__(512) void inr_forward_kernel(const InrArgs a) {
     if (pendIdx >= 0) a.argmax[pendIdx] = pendVal;
 }
 
+// =====================================================================================================
+// Weight-stationary kernel for BASELINE config 5's network: the 4 x 256 SIREN on (coords, 4 modalities),
+// 7 -> 256 -> 256 -> 256 -> 256 -> (<= 4 classes)   (notebooks/neumors_inr.ipynb:853-899,1165-1178).
+//
+// Why a second dataflow.  Measured on the streaming kernel above (profiles/r02_inr_knockouts.txt): with the
+// weight LDS-DMA compiled out it runs 24.7 -> 18.8 ms, with the input staging compiled out 24.7 -> 20.1 ms.  A SIMD
+// has 32 issue cycles per MFMA; the stream spends ~12 of them per MFMA on DMA pieces (416 KiB of weights pass
+// through LDS for every 256 points, and the point count per CU is capped by the register file that holds the
+// activations).  Here the roles are swapped: the WEIGHTS live in the register file for the whole launch — a
+// CU's four SIMDs hold 4 x 128 KiB of registers, the network is 416 KiB — and the ACTIVATIONS travel through
+// LDS.  One wave per SIMD (512 registers); wave w owns out tiles 2w and 2w+1 of every layer (416 registers of
+// A fragments: 16 layer-0, 3 x 128 hidden, 16 head); a round is G = 4 groups of 32 points; per layer a wave reads
+// a group's sixteen 1-KiB B fragments from LDS (what all four waves wrote in the previous phase), runs its
+// 2 x 16 MFMAs, and writes its two out tiles back as the next layer's B fragments 4w .. 4w+3 (the accumulator
+// layout IS the B layout, as above: two ds_write_b128 per tile).  The head is split over k: wave w multiplies
+// its own 64 output features of the last hidden layer (still in registers) with its slice of the head and
+// leaves 4 partial logits per point in LDS; wave g sums the four partials of group g in a fixed order.  No weight
+// traffic at all after the prologue, one workgroup barrier per layer phase (128 MFMAs per wave apart).
+// Same packed image, same arithmetic per point (accumulator starts at the bias, k steps in ascending order):
+// bit-identical logits to the streaming kernel for the hidden layers' inputs; the head sums four k-quarter
+// partials in fp32 instead of one running chain, so logits may differ from it in the last bit (the tests hold both
+// kernels to the same fp32 / fp64 references, and each is batch-position invariant by construction).
+// =====================================================================================================
+constexpr int kWsGroups = 3;
+
+// MFMA with the operand register class spelled out.  hipcc's allocator fills the 256 arch VGPRs with weights first
+// and then shuttles everything VALU touches through v_accvgpr moves (measured: 220 VGPRs of weights, 520
+// v_accvgpr_read per round, 21 fragments spilled to scratch and reloaded every round).  An "a" constraint pins a
+// fragment into the accumulation half of the unified file — which VALU cannot use anyway — and leaves the arch
+// half to the accumulators, the B ring and the activation.  The compiler does not know these are matrix
+// instructions, so the MFMA -> VALU read hazard is kept by construction (see the call sites) or by mfma_drain(acc).
+__device__ __forceinline__ void mfma_a(f32x16& acc, const bf16x8& wa, const bf16x8& b) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(wa), "v"(b));
+}
+__device__ __forceinline__ void mfma_v(f32x16& acc, const bf16x8& wv, const bf16x8& b) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(wv), "v"(b));
+}
+// after the last MFMA of a chain whose result VALU reads next: 8 passes + 3 wait states, taken generously
+// (the accumulator is an in/out operand so that no read of it can be scheduled above the wait)
+__device__ __forceinline__ void mfma_drain(f32x16& acc) { asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc)); }
+
+template <bool SIREN>
+__global__ __launch_bounds__(256, 1) void inr_ws_kernel(const InrArgs a) {
+    constexpr int G = kWsGroups, NH = 3, KS = 16, RD = 4;
+    constexpr int kActQ = G * 2 * KS * 64;               // uint4: [group][parity][k step][lane]   128 KiB
+    constexpr int kInQ = G * 2 * 64;                     // layer-0 B fragments (k steps 0, 1)       8 KiB
+    constexpr int kPartQ = G * 4 * 32;                   // head partials [group][wave][point]       8 KiB
+    constexpr int kBiasQ = (4 * 256 + 32) / 4;           // padded biases                          4.1 KiB
+    constexpr int kW0Q = 16 * 64, kWoQ = 16 * 64;        // layer-0 and head A fragments (all waves')   16 + 16 KiB
+    constexpr int kW0Off = kActQ + kInQ + kPartQ + kBiasQ, kWoOff = kW0Off + kW0Q;
+    __shared__ uint4 ldsAll[kActQ + kInQ + kPartQ + kBiasQ + kW0Q + kWoQ];
+    uint4* const ldsAct = ldsAll;
+    uint4* const ldsIn = ldsAll + kActQ;
+    float4* const ldsPart = reinterpret_cast<float4*>(ldsAll + kActQ + kInQ);
+    const float4* const ldsBias = reinterpret_cast<const float4*>(ldsAll + kActQ + kInQ + kPartQ);
+
+    int64_t nPts = a.n;
+    if (a.nDev != nullptr) { const int64_t nd = (int64_t)*a.nDev; nPts = nd < nPts ? nd : nPts; }
+    if (nPts <= 0) return;
+
+    const uint32_t lane = threadIdx.x & 63u, r = lane & 31u, h = lane >> 5;
+    const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    {   // biases -> LDS once (scaled like the packed weights: see InrLayout::bscale)
+        const uint32_t nq = (a.L.biasOff[a.L.numLayers - 1] + 32) / 4;
+        for (uint32_t i = threadIdx.x; i < nq; i += blockDim.x) {
+            uint32_t l = 0;
+            while (l + 1 < a.L.numLayers && 4 * i >= a.L.biasOff[l + 1]) ++l;
+            float4 b = reinterpret_cast<const float4*>(a.bias)[i];
+            const float sc = a.L.bscale[l];
+            b.x *= sc; b.y *= sc; b.z *= sc; b.w *= sc;
+            ldsAll[kActQ + kInQ + kPartQ + i] = __builtin_bit_cast(uint4, b);
+        }
+    }
+    // ---- the network, resident in this wave's registers --------------------------------------------------
+    const uint4* __restrict__ wp = a.wpack;
+    bf16x8 Wh[NH][2][KS];                                 // 384 registers: the three hidden matrices' out tiles 2w, 2w+1
+#pragma unroll
+    for (int l = 0; l < NH; ++l)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                Wh[l][j][ks] = __builtin_bit_cast(bf16x8, wp[(size_t)(a.L.fragOff[l + 1] + (2 * w + j) * KS + ks) * 64 + lane]);
+    // layer 0 (2 k steps per out tile) and the head (k-quarter per wave) are 4 + 4 fragments per wave: they stay in
+    // LDS (lane-linear, read just before use) — 400 + of the 512 registers as weights left the allocator no room
+    for (uint32_t f = w; f < 16; f += 4) {
+        ldsAll[kW0Off + f * 64 + lane] = wp[(size_t)(a.L.fragOff[0] + f) * 64 + lane];          // [tile o][s] = fragment 2o + s
+        ldsAll[kWoOff + f * 64 + lane] = wp[(size_t)(a.L.fragOff[NH + 1] + f) * 64 + lane];     // head k step f
+    }
+    // LDS addressing: a handful of per-lane base pointers (re-laundered every round so that the compiler cannot
+    // expand them into one hoisted VGPR per fragment address and spill) + compile-time immediates (<= 64 KiB each).
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));       // plain vector types: HIP's uint4 / float4 classes
+    typedef float f32x4 __attribute__((ext_vector_type(4)));          // cannot be assigned through an LDS-qualified pointer
+    typedef __attribute__((address_space(3))) u32x4 lds_q;
+    typedef __attribute__((address_space(3))) f32x4 lds_f4;
+    lds_q* bR = (lds_q*)ldsAll + lane;                               // B-fragment reads: fragment f at bR[64 f]
+    lds_q* bW = (lds_q*)ldsAll + 4 * w * 64 + lane;                  // this wave's output fragments 4w .. 4w+3
+    lds_q* bIn = (lds_q*)ldsAll + kActQ + lane;                      // layer-0 B fragments
+    lds_f4* bPart = (lds_f4*)((lds_q*)ldsAll + kActQ + kInQ) + w * 32 + r;
+    lds_f4* bBias = (lds_f4*)((lds_q*)ldsAll + kActQ + kInQ + kPartQ) + 16 * w + h;      // tile 2w, rows 4h..
+    lds_q* bWt = (lds_q*)ldsAll + kW0Off + 4 * w * 64 + lane;        // this wave's layer-0 fragments 4w..4w+3; head: + kW0Q
+    auto launder = [&]() {
+        uint32_t v0 = (uint32_t)(uintptr_t)bR, v1 = (uint32_t)(uintptr_t)bW, v2 = (uint32_t)(uintptr_t)bIn,
+                 v3 = (uint32_t)(uintptr_t)bPart, v4 = (uint32_t)(uintptr_t)bBias, v5 = (uint32_t)(uintptr_t)bWt;
+        asm volatile("" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5));
+        bWt = (lds_q*)(uintptr_t)v5;
+        bR = (lds_q*)(uintptr_t)v0; bW = (lds_q*)(uintptr_t)v1; bIn = (lds_q*)(uintptr_t)v2;
+        bPart = (lds_f4*)(uintptr_t)v3; bBias = (lds_f4*)(uintptr_t)v4;
+    };
+    // biases of this specialised network sit at layer l -> 256 l (head: 1024): compile-time immediates
+    auto bias_tile = [&](int l, int j) {                                 // tile 2w + j: rows 8g + 4h .. +3 (g = 0..3)
+        f32x16 acc;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 b = bBias[(256 * l + 32 * j + 8 * g) >> 2];
+            acc[4 * g + 0] = b.x; acc[4 * g + 1] = b.y; acc[4 * g + 2] = b.z; acc[4 * g + 3] = b.w;
+        }
+        return acc;
+    };
+    auto rd_frag = [&](int g, int par, int ks) { return __builtin_bit_cast(bf16x8, bR[((g * 2 + par) * KS + ks) * 64]); };
+    auto wr_frag = [&](int g, int par, int j, int s2, const bf16x8& v) { bW[((g * 2 + par) * KS + 2 * j + s2) * 64] = __builtin_bit_cast(u32x4, v); };
+
+    // raw inputs of point `pidx` -> the two layer-0 B fragments of the augmented split (see make_layout):
+    //   k step 0 = [x_hi(0..6), x_lo(0..6), 0, 0],  k step 1 = [x_hi(0..6), 0 ...]; element j of lane half h is slot 8(j>>2) + 4h + (j&3)
+    float rawc[3];
+    float4 rawf;
+    auto load_raw = [&](int64_t pidx) {
+        const int64_t p = pidx < nPts ? pidx : nPts - 1;
+        rawc[0] = a.coords[p * 3 + 0]; rawc[1] = a.coords[p * 3 + 1]; rawc[2] = a.coords[p * 3 + 2];
+        rawf = reinterpret_cast<const float4*>(a.feats)[p];
+    };
+    auto stage_raw = [&](int g) {
+        const float x[7] = { rawc[0], rawc[1], rawc[2], rawf.x, rawf.y, rawf.z, rawf.w };
+        __bf16 hi[8], lo[8];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) { hi[k] = (__bf16)x[k]; lo[k] = (__bf16)(x[k] - (float)hi[k]); }
+        hi[7] = (__bf16)0.0f; lo[7] = (__bf16)0.0f;
+        const __bf16 z = (__bf16)0.0f;
+        bf16x8 f0, f1;
+        // lane half 0: slots 0..3, 8..11        lane half 1: slots 4..7, 12..15
+        const bf16x8 f0a = { hi[0], hi[1], hi[2], hi[3], lo[1], lo[2], lo[3], lo[4] };
+        const bf16x8 f0b = { hi[4], hi[5], hi[6], lo[0], lo[5], lo[6], z, z };
+        const bf16x8 f1a = { hi[0], hi[1], hi[2], hi[3], z, z, z, z };
+        const bf16x8 f1b = { hi[4], hi[5], hi[6], z, z, z, z, z };
+        f0 = h ? f0b : f0a;
+        f1 = h ? f1b : f1a;
+        lds_q* dst = (lds_q*)ldsAll + kActQ + g * 2 * 64 + lane;      // g = this wave's id: runtime, once per round
+        dst[0] = __builtin_bit_cast(u32x4, f0);
+        dst[64] = __builtin_bit_cast(u32x4, f1);
+    };
+
+    // one value of a finished accumulator per call: activation, and every second value the packed bf16 convert
+    auto act_one = [&](f32x16& ap, bf16x8 (&Ho)[2], int i) {
+        if constexpr (SIREN) ap[i] = __builtin_amdgcn_sinf(ap[i]);
+        if (i & 1) {
+            f32x2 x = { ap[i - 1], ap[i] };
+            if constexpr (!SIREN) x = __builtin_elementwise_max(x, (f32x2){ 0.0f, 0.0f });
+            Ho[i >> 3][(i & 7) - 1] = (__bf16)x.x;
+            Ho[i >> 3][i & 7] = (__bf16)x.y;
+        }
+    };
+
+    // Head (linear, <= 4 classes): one out tile, so one wave per group — wave g reads group g's last hidden outputs
+    // (parity NH & 1 ^ 1 ... written by all four waves before the barrier that precedes this) and the sixteen head
+    // fragments from LDS, and stores logits / argmax.  np.argmax = first maximum.
+    auto head = [&](int64_t rnd) {
+        constexpr int par = (NH & 1) ^ 1;
+        f32x16 acc;
+        {
+            const f32x4 hb = *((lds_f4*)((lds_q*)ldsAll + kActQ + kInQ + kPartQ) + (1024 >> 2) + h);   // rows 4h..4h+3 of the head's bias
+            acc = (f32x16)(0.0f);
+            acc[0] = hb.x; acc[1] = hb.y; acc[2] = hb.z; acc[3] = hb.w;
+        }
+        lds_q* bH = (lds_q*)ldsAll + (w * 2 + par) * KS * 64 + lane;
+        lds_q* bWo = (lds_q*)ldsAll + kWoOff + lane;
+        asm volatile("s_nop 3" : "+v"(acc));                             // VALU wrote acc (v_mov): two wait states before an MFMA reads it as C
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 wa = __builtin_bit_cast(bf16x8, bWo[ks * 64]), hb8 = __builtin_bit_cast(bf16x8, bH[ks * 64]);
+            mfma_v(acc, wa, hb8);
+        }
+        mfma_drain(acc);
+        const int64_t pidx = (rnd * G + w) * 32 + r;
+        if (h == 0 && pidx < nPts) {                                      // classes 0..3 are rows 0..3: lane half 0, registers 0..3
+            const float v[4] = { acc[0], acc[1], acc[2], acc[3] };
+            if (a.logits != nullptr)
+                for (uint32_t c = 0; c < a.L.outDim; ++c) a.logits[pidx * a.L.outDim + c] = v[c];
+            if (a.argmax != nullptr) {
+                float best = -INFINITY;
+                uint32_t bestc = 0;
+#pragma unroll
+                for (uint32_t c = 0; c < 4; ++c) {
+                    const float vc = c < a.L.outDim ? v[c] : -INFINITY;
+                    const bool take = vc > best;                            // strict: the first maximum
+                    best = take ? vc : best;
+                    bestc = take ? c : bestc;
+                }
+                a.argmax[pidx] = (int16_t)bestc;
+            }
+        }
+    };
+
+    const int64_t nRounds = (nPts + G * 32 - 1) / (G * 32);
+    int64_t round = blockIdx.x;
+    if (w < G) {                                           // wave w stages (and later reduces) group w
+        load_raw((round * G + w) * 32 + r);
+        stage_raw((int)w);
+    }
+    __syncthreads();                                       // biases + first inputs are in LDS
+    int64_t prevRound = -1;
+
+    for (; round < nRounds; round += gridDim.x) {
+        const int64_t nextRound = round + gridDim.x;
+        launder();
+        // ---- head of the previous round: wave g takes group g (16 k steps over the last hidden layer's outputs) ----
+        if (prevRound >= 0 && w < G) head(prevRound);
+        // ---- layer 0: two k steps per out tile (augmented hi/lo split), writes parity 1 ------------------------
+        {
+            bf16x8 W0[2][2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) W0[j][s2] = __builtin_bit_cast(bf16x8, bWt[(2 * j + s2) * 64]);
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const bf16x8 B0 = __builtin_bit_cast(bf16x8, bIn[(g * 2 + 0) * 64]);
+                const bf16x8 B1 = __builtin_bit_cast(bf16x8, bIn[(g * 2 + 1) * 64]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    // fences: without them the scheduler hoists every pass's bias reads to the top of the phase
+                    // (6 x 16 registers) and the allocator evicts a layer of weights to scratch
+                    __builtin_amdgcn_sched_barrier(0);
+                    f32x16 acc = bias_tile(0, j);
+                    mfma_v(acc, W0[j][0], B0);
+                    mfma_v(acc, W0[j][1], B1);
+                    mfma_drain(acc);
+                    bf16x8 Ho[2];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) act_one(acc, Ho, i);
+                    wr_frag(g, 1, j, 0, Ho[0]);
+                    wr_frag(g, 1, j, 1, Ho[1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        __syncthreads();
+        // ---- hidden layers: layer l reads parity (l & 1), writes the other; the last one feeds the head ---------
+        auto hidden = [&](auto lC) {
+            constexpr int l = decltype(lC)::value;            // 1 .. NH
+            constexpr int par = l & 1;
+            constexpr int NP = 2 * G;                          // tile passes: (group g, tile j) = (i >> 1, i & 1)
+            bf16x8 ring[RD];
+#pragma unroll
+            for (int d = 0; d < RD; ++d) ring[d] = rd_frag(0, par, d);
+            f32x16 accPrev;
+            bf16x8 Ho[2];                                      // packed outputs of the previous pass
+            f32x16 acc = bias_tile(l, 0);
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                const int j = i & 1;
+                f32x16 accNext;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const int q = i * KS + ks;                 // position in the phase's B-fragment stream
+                    if constexpr (l <= 2) mfma_a(acc, Wh[l - 1][j][ks], ring[q % RD]);             // layers 1, 2: the 256 AGPRs
+                    else mfma_v(acc, Wh[l - 1][j][ks], ring[q % RD]);                               // layer 3: 128 arch VGPRs
+                    if (q + RD < NP * KS) ring[q % RD] = rd_frag((q + RD) / KS >> 1, par, (q + RD) % KS);
+                    if (i > 0) {
+                        // the previous pass's accumulator: two values per step over steps 2..9.  The compiler does not know
+                        // the asm statements are MFMAs, so the XDL-write -> VALU-read wait (8 passes + 3 states) is kept by
+                        // hand: two MFMA issues and 16 idle states in step 1's otherwise empty gap
+                        const int pg = (i - 1) >> 1, pj = (i - 1) & 1;
+                        if (ks == 1) asm volatile("s_nop 15" : "+v"(accPrev));   // + two MFMA issues since the producer: > 8 passes + 3
+                        if (ks >= 2 && ks <= 9) { act_one(accPrev, Ho, 2 * ks - 4); act_one(accPrev, Ho, 2 * ks - 3); }
+                        if (ks == 6) wr_frag(pg, par ^ 1, pj, 0, Ho[0]);
+                        if (ks == 10) wr_frag(pg, par ^ 1, pj, 1, Ho[1]);
+                    }
+                    if (ks == 12 && i + 1 < NP) accNext = bias_tile(l, (i + 1) & 1);                // lands in accPrev's registers
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                accPrev = acc;
+                if (i + 1 < NP) acc = accNext;
+            }
+            // the phase's last pass
+            mfma_drain(accPrev);
+#pragma unroll
+            for (int v = 0; v < 16; ++v) act_one(accPrev, Ho, v);
+            wr_frag(G - 1, par ^ 1, 1, 0, Ho[0]);
+            wr_frag(G - 1, par ^ 1, 1, 1, Ho[1]);
+        };
+        hidden(IC<1>{});
+        __syncthreads();
+        hidden(IC<2>{});
+        __syncthreads();
+        if (nextRound < nRounds && w < G) load_raw((nextRound * G + w) * 32 + r);      // in flight under the last hidden phase
+        hidden(IC<3>{});
+        if (nextRound < nRounds && w < G) stage_raw((int)w);                          // ldsIn was last read before two barriers
+        __syncthreads();
+        prevRound = round;
+    }
+    // the last round's head
+    if (prevRound >= 0 && w < G) head(prevRound);
+}
+
+// nets the weight-stationary kernel takes: the 7-input SIREN with four 256-wide layers and <= 4 classes, points mode
+static bool ws_eligible(const InrArgs& a) {
+    return a.kind == MRIRT_INR_SIREN && a.L.aug0 && a.L.hidden == 256 && a.L.numLayers == 5 && a.L.outDim <= 4 &&
+           a.M == 4 && !a.volume && (reinterpret_cast<uintptr_t>(a.feats) & 15u) == 0;
+}
+
+static int launch_inr_ws(const InrArgs& a, hipStream_t s) {
+    int dev = 0, cus = 0;
+    MRIRT_HIP(hipGetDevice(&dev));
+    MRIRT_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const int64_t rounds = (a.n + kWsGroups * 32 - 1) / (kWsGroups * 32);
+    const int64_t nres = cus > 0 ? cus : 256;                  // one workgroup per CU (149 KiB of LDS, 512 registers)
+    const dim3 grid((uint32_t)(rounds < nres ? rounds : nres)), block(256);
+    hipLaunchKernelGGL(inr_ws_kernel<true>, grid, block, 0, s, a);
+    MRIRT_HIP(hipGetLastError());
+    return MRIRT_OK;
+}
+
 template <int HID>
 static int launch_inr_kt0(const InrArgs& a, hipStream_t s) {
     const int64_t groups = (a.n + kInrWaves * 32 - 1) / (kInrWaves * 32);
@@ -600,6 +943,7 @@ static int launch_inr_kt0(const InrArgs& a, hipStream_t s) {
 
 static int launch_inr(const InrArgs& a, hipStream_t s) {
     if (a.n <= 0) return MRIRT_OK;
+    if (ws_eligible(a) && getenv("MRIRT_INR_NO_WS") == nullptr) return launch_inr_ws(a, s);
     if ((a.n + kInrWaves * 32 - 1) / (kInrWaves * 32) >= (1ll << 31)) return MRIRT_ERR_ARG;
     switch (a.L.hidden) {
         case 32: return launch_inr_kt0<32>(a, s);
