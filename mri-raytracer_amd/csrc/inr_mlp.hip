@@ -604,6 +604,18 @@ __global__ __launch_bounds__(512) void inr_forward_kernel(const InrArgs a) {
 // kernels to the same fp32 / fp64 references, and each is batch-position invariant by construction).
 // =====================================================================================================
 constexpr int kWsGroups = 3;
+// Diagnostic build (-DMRIRT_WS_STAMPS): s_memtime at the phase boundaries of one steady-state round of every
+// workgroup goes to the logits buffer (which then holds no logits): [block][wave][24] uint64.  Never in the product.
+#ifdef MRIRT_WS_STAMPS
+#define WS_STAMP(k) do { if (stampRound && lane == 0) stamps[((size_t)blockIdx.x * 4 + w) * 24 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define WS_STAMP(k) do { } while (0)
+#endif
+#ifdef MRIRT_WS_NOBAR
+#define WS_SYNC() do { } while (0)
+#else
+#define WS_SYNC() __syncthreads()
+#endif
 
 // MFMA with the operand register class spelled out.  hipcc's allocator fills the 256 arch VGPRs with weights first
 // and then shuttles everything VALU touches through v_accvgpr moves (measured: 220 VGPRs of weights, 520
@@ -623,7 +635,10 @@ __device__ __forceinline__ void mfma_drain(f32x16& acc) { asm volatile("s_nop 15
 
 template <bool SIREN>
 __global__ __launch_bounds__(256, 1) void inr_ws_kernel(const InrArgs a) {
-    constexpr int G = kWsGroups, NH = 3, KS = 16, RD = 4;
+#ifndef MRIRT_WS_RD
+#define MRIRT_WS_RD 6
+#endif
+    constexpr int G = kWsGroups, NH = 3, KS = 16, RD = MRIRT_WS_RD;      // RD: B fragments in flight ahead of their MFMA
     constexpr int kActQ = G * 2 * KS * 64;               // uint4: [group][parity][k step][lane]   128 KiB
     constexpr int kInQ = G * 2 * 64;                     // layer-0 B fragments (k steps 0, 1)       8 KiB
     constexpr int kPartQ = G * 4 * 32;                   // head partials [group][wave][point]       8 KiB
@@ -733,7 +748,9 @@ __global__ __launch_bounds__(256, 1) void inr_ws_kernel(const InrArgs a) {
 
     // one value of a finished accumulator per call: activation, and every second value the packed bf16 convert
     auto act_one = [&](f32x16& ap, bf16x8 (&Ho)[2], int i) {
+#ifndef MRIRT_WS_NOSIN
         if constexpr (SIREN) ap[i] = __builtin_amdgcn_sinf(ap[i]);
+#endif
         if (i & 1) {
             f32x2 x = { ap[i - 1], ap[i] };
             if constexpr (!SIREN) x = __builtin_elementwise_max(x, (f32x2){ 0.0f, 0.0f });
@@ -756,17 +773,23 @@ __global__ __launch_bounds__(256, 1) void inr_ws_kernel(const InrArgs a) {
         lds_q* bH = (lds_q*)ldsAll + (w * 2 + par) * KS * 64 + lane;
         lds_q* bWo = (lds_q*)ldsAll + kWoOff + lane;
         asm volatile("s_nop 3" : "+v"(acc));                             // VALU wrote acc (v_mov): two wait states before an MFMA reads it as C
+        bf16x8 ra[4], rb[4];                                              // four k steps of operands in flight
+#pragma unroll
+        for (int d = 0; d < 4; ++d) { ra[d] = __builtin_bit_cast(bf16x8, bWo[d * 64]); rb[d] = __builtin_bit_cast(bf16x8, bH[d * 64]); }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const bf16x8 wa = __builtin_bit_cast(bf16x8, bWo[ks * 64]), hb8 = __builtin_bit_cast(bf16x8, bH[ks * 64]);
-            mfma_v(acc, wa, hb8);
+            mfma_v(acc, ra[ks % 4], rb[ks % 4]);
+            if (ks + 4 < KS) { ra[ks % 4] = __builtin_bit_cast(bf16x8, bWo[(ks + 4) * 64]); rb[ks % 4] = __builtin_bit_cast(bf16x8, bH[(ks + 4) * 64]); }
+            __builtin_amdgcn_sched_barrier(0);
         }
         mfma_drain(acc);
         const int64_t pidx = (rnd * G + w) * 32 + r;
         if (h == 0 && pidx < nPts) {                                      // classes 0..3 are rows 0..3: lane half 0, registers 0..3
             const float v[4] = { acc[0], acc[1], acc[2], acc[3] };
+#ifndef MRIRT_WS_STAMPS
             if (a.logits != nullptr)
                 for (uint32_t c = 0; c < a.L.outDim; ++c) a.logits[pidx * a.L.outDim + c] = v[c];
+#endif
             if (a.argmax != nullptr) {
                 float best = -INFINITY;
                 uint32_t bestc = 0;
@@ -794,38 +817,115 @@ __global__ __launch_bounds__(256, 1) void inr_ws_kernel(const InrArgs a) {
     for (; round < nRounds; round += gridDim.x) {
         const int64_t nextRound = round + gridDim.x;
         launder();
-        // ---- head of the previous round: wave g takes group g (16 k steps over the last hidden layer's outputs) ----
-        if (prevRound >= 0 && w < G) head(prevRound);
-        // ---- layer 0: two k steps per out tile (augmented hi/lo split), writes parity 1 ------------------------
-        {
-            bf16x8 W0[2][2];
+#ifdef MRIRT_WS_STAMPS
+        uint64_t* stamps = reinterpret_cast<uint64_t*>(a.logits);
+        const bool stampRound = stamps != nullptr && round == (int64_t)blockIdx.x + 3 * (int64_t)gridDim.x;
+#endif
+        WS_STAMP(0);
+        // ---- layer 0 of this round + head of the previous one, interleaved ------------------------------------
+        // Layer 0 is VALU-bound (2 MFMAs but 16 sines per tile pass), the head is MFMA-bound (16 MFMAs, no activation),
+        // and run one after the other they cost a sixth of a round (profiles/r02_inr_ws_knockouts.txt).  Here pass
+        // i's activation is sliced under pass i+1's MFMAs and two or three head MFMAs (waves 0..G-1: wave g takes
+        // group g of the PREVIOUS round, sixteen k steps over the last hidden layer's outputs) per pass.
+#if !defined(MRIRT_WS_NOL0)
+        auto l0_head = [&](auto headC) {
+            constexpr bool HEAD = decltype(headC)::value;
+            constexpr int hpar = (NH & 1) ^ 1;                // parity the last hidden layer wrote
+            lds_q* bH = (lds_q*)ldsAll + (w * 2 + hpar) * KS * 64 + lane;
+            lds_q* bWo = (lds_q*)ldsAll + kWoOff + lane;
+            f32x16 hacc;
+            bf16x8 ra[2], rb[2];                               // head operands, two k steps ahead
+            if constexpr (HEAD) {
+                const f32x4 hb = *((lds_f4*)((lds_q*)ldsAll + kActQ + kInQ + kPartQ) + (1024 >> 2) + h);   // rows 4h..4h+3 of the head's bias
+                hacc = (f32x16)(0.0f);
+                hacc[0] = hb.x; hacc[1] = hb.y; hacc[2] = hb.z; hacc[3] = hb.w;
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+                for (int d = 0; d < 2; ++d) { ra[d] = __builtin_bit_cast(bf16x8, bWo[d * 64]); rb[d] = __builtin_bit_cast(bf16x8, bH[d * 64]); }
+                asm volatile("s_nop 3" : "+v"(hacc));          // VALU wrote hacc (v_mov): wait states before an MFMA reads it as C
+            }
+            int hk = 0;                                        // head k step (a compile-time value in the unrolled code)
+            auto head_step = [&]() {
+                if constexpr (HEAD) {
+                    if (hk < KS) {
+                        mfma_v(hacc, ra[hk % 2], rb[hk % 2]);
+                        if (hk + 2 < KS) { ra[hk % 2] = __builtin_bit_cast(bf16x8, bWo[(hk + 2) * 64]); rb[hk % 2] = __builtin_bit_cast(bf16x8, bH[(hk + 2) * 64]); }
+                        ++hk;
+                    }
+                }
+            };
+            constexpr int NP = 2 * G;
+            f32x16 acc = bias_tile(0, 0), accPrev, accNext;
+            bf16x8 Ho[2], Bin[2];
 #pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) W0[j][s2] = __builtin_bit_cast(bf16x8, bWt[(2 * j + s2) * 64]);
+            for (int i = 0; i < NP; ++i) {
+                const int g = i >> 1, j = i & 1;
+                if (j == 0) { Bin[0] = __builtin_bit_cast(bf16x8, bIn[(g * 2 + 0) * 64]); Bin[1] = __builtin_bit_cast(bf16x8, bIn[(g * 2 + 1) * 64]); }
+                const bf16x8 wa0 = __builtin_bit_cast(bf16x8, bWt[(2 * j + 0) * 64]), wa1 = __builtin_bit_cast(bf16x8, bWt[(2 * j + 1) * 64]);
+                mfma_v(acc, wa0, Bin[0]);
+                mfma_v(acc, wa1, Bin[1]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (i + 1 < NP) accNext = bias_tile(0, (i + 1) & 1);
+                if (i > 0) {
+                    const int pg = (i - 1) >> 1, pj = (i - 1) & 1;
+                    asm volatile("s_nop 15" : "+v"(accPrev));   // two MFMA issues + 16 states since accPrev's producer
 #pragma unroll
-            for (int g = 0; g < G; ++g) {
-                const bf16x8 B0 = __builtin_bit_cast(bf16x8, bIn[(g * 2 + 0) * 64]);
-                const bf16x8 B1 = __builtin_bit_cast(bf16x8, bIn[(g * 2 + 1) * 64]);
+                    for (int v = 0; v < 16; ++v) {
+                        act_one(accPrev, Ho, v);
+                        if (v == 3 || v == 9 || (v == 14 && i < 5)) { head_step(); __builtin_amdgcn_sched_barrier(0); }
+                        if (v == 7) wr_frag(pg, 1, pj, 0, Ho[0]);
+                    }
+                    wr_frag(pg, 1, pj, 1, Ho[1]);
+                } else {
+                    head_step(); head_step(); head_step();
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                accPrev = acc;
+                if (i + 1 < NP) acc = accNext;
+            }
+            // the last pass's activation, under whatever is left of the head
+            head_step();
+            mfma_drain(accPrev);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    // fences: without them the scheduler hoists every pass's bias reads to the top of the phase
-                    // (6 x 16 registers) and the allocator evicts a layer of weights to scratch
-                    __builtin_amdgcn_sched_barrier(0);
-                    f32x16 acc = bias_tile(0, j);
-                    mfma_v(acc, W0[j][0], B0);
-                    mfma_v(acc, W0[j][1], B1);
-                    mfma_drain(acc);
-                    bf16x8 Ho[2];
+            for (int v = 0; v < 16; ++v) {
+                act_one(accPrev, Ho, v);
+                if (v == 5 || v == 11) head_step();
+            }
+            wr_frag(G - 1, 1, 1, 0, Ho[0]);
+            wr_frag(G - 1, 1, 1, 1, Ho[1]);
+            if constexpr (HEAD) {
+                while (hk < KS) head_step();                   // (none left with G = 3: 3 + 3*4 ... counted at compile time)
+                mfma_drain(hacc);
+                const int64_t pidx = (prevRound * G + w) * 32 + r;
+                if (h == 0 && pidx < nPts) {                   // classes 0..3 are rows 0..3: lane half 0, registers 0..3
+                    const float v[4] = { hacc[0], hacc[1], hacc[2], hacc[3] };
+#ifndef MRIRT_WS_STAMPS
+                    if (a.logits != nullptr)
+                        for (uint32_t c = 0; c < a.L.outDim; ++c) a.logits[pidx * a.L.outDim + c] = v[c];
+#endif
+                    if (a.argmax != nullptr) {
+                        float best = -INFINITY;
+                        uint32_t bestc = 0;
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) act_one(acc, Ho, i);
-                    wr_frag(g, 1, j, 0, Ho[0]);
-                    wr_frag(g, 1, j, 1, Ho[1]);
-                    __builtin_amdgcn_sched_barrier(0);
+                        for (uint32_t c = 0; c < 4; ++c) {
+                            const float vc = c < a.L.outDim ? v[c] : -INFINITY;
+                            const bool take = vc > best;        // strict: the first maximum
+                            best = take ? vc : best;
+                            bestc = take ? c : bestc;
+                        }
+                        a.argmax[pidx] = (int16_t)bestc;
+                    }
                 }
             }
-        }
-        __syncthreads();
+        };
+#ifdef MRIRT_WS_NOHEAD
+        l0_head(IC<0>{});
+#else
+        if (prevRound >= 0 && w < G) l0_head(IC<1>{}); else l0_head(IC<0>{});
+#endif
+#endif
+        WS_STAMP(1);
+        WS_SYNC();
+        WS_STAMP(2);
         // ---- hidden layers: layer l reads parity (l & 1), writes the other; the last one feeds the head ---------
         auto hidden = [&](auto lC) {
             constexpr int l = decltype(lC)::value;            // 1 .. NH
@@ -841,6 +941,7 @@ __global__ __launch_bounds__(256, 1) void inr_ws_kernel(const InrArgs a) {
             for (int i = 0; i < NP; ++i) {
                 const int j = i & 1;
                 f32x16 accNext;
+                if constexpr (l == 1) WS_STAMP(8 + i);
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     const int q = i * KS + ks;                 // position in the phase's B-fragment stream
@@ -864,6 +965,7 @@ __global__ __launch_bounds__(256, 1) void inr_ws_kernel(const InrArgs a) {
                 if (i + 1 < NP) acc = accNext;
             }
             // the phase's last pass
+            if constexpr (l == 1) WS_STAMP(8 + NP);
             mfma_drain(accPrev);
 #pragma unroll
             for (int v = 0; v < 16; ++v) act_one(accPrev, Ho, v);
@@ -871,13 +973,18 @@ __global__ __launch_bounds__(256, 1) void inr_ws_kernel(const InrArgs a) {
             wr_frag(G - 1, par ^ 1, 1, 1, Ho[1]);
         };
         hidden(IC<1>{});
-        __syncthreads();
+        WS_STAMP(3);
+        WS_SYNC();
         hidden(IC<2>{});
-        __syncthreads();
+        WS_STAMP(4);
+        WS_SYNC();
+        WS_STAMP(5);
         if (nextRound < nRounds && w < G) load_raw((nextRound * G + w) * 32 + r);      // in flight under the last hidden phase
         hidden(IC<3>{});
+        WS_STAMP(6);
         if (nextRound < nRounds && w < G) stage_raw((int)w);                          // ldsIn was last read before two barriers
-        __syncthreads();
+        WS_SYNC();
+        WS_STAMP(7);
         prevRound = round;
     }
     // the last round's head

@@ -1,0 +1,115 @@
+// Micro-benchmark: cycles per v_mfma_f32_32x32x16_bf16 in a dependent chain, by operand register class and with /
+// without a ds_read_b128 + s_waitcnt in every gap.  One wave per SIMD (256-thread block), one block per CU.
+//   hipcc -O3 --offload-arch=gfx950 tools/micro/mfma_pace.hip -o /tmp/mfma_pace && /tmp/mfma_pace
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include <algorithm>
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <int MODE>
+__global__ __launch_bounds__(256, 1) void k(const uint4* __restrict__ w, unsigned long long* out, float* sink) {
+    __shared__ u32x4 lds[16 * 64];
+    const int lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < 16 * 64; i += 256) lds[i] = (u32x4){ (unsigned)i, 1u, 2u, 3u };
+    __syncthreads();
+    bf16x8 A[16], B[4];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) A[i] = __builtin_bit_cast(bf16x8, w[i * 64 + lane]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) B[i] = __builtin_bit_cast(bf16x8, w[(16 + i) * 64 + lane]);
+    f32x16 acc = (f32x16)(0.0f);
+    bf16x8 Br[8];
+    for (int i = 0; i < 8; ++i) Br[i] = B[i & 3];
+    float x0 = 0.3f * lane, x1 = 0.7f * lane;
+    typedef __attribute__((address_space(3))) u32x4 lq;
+    lq* base = (lq*)lds + lane;
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < 64; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if (MODE == 0) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(A[i]), "v"(B[i & 3]));
+            if (MODE == 1) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "a"(A[i]), "v"(B[i & 3]));
+            if (MODE == 2) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(A[i]), "v"(B[i & 3]));
+            if (MODE == 3 || MODE == 4) {   // with an LDS read refilling the B ring every step
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(A[i]), "v"(B[i & 3]));
+                B[i & 3] = __builtin_bit_cast(bf16x8, base[((i + it) & 15) * 64]);
+                if (MODE == 4) { acc[0] = __builtin_amdgcn_sinf(acc[0] * 0.0f + 1.0f * i); }   // (breaks the chain: not used)
+            }
+            if (MODE == 7 || MODE == 8 || MODE == 9) {   // immediate-offset LDS read (as the kernel's B ring), ring of 4 / 8
+                constexpr int RDm = MODE == 8 ? 8 : 4;
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(A[i]), "v"(Br[i % RDm]));
+                Br[i % RDm] = __builtin_bit_cast(bf16x8, base[i * 64]);
+                if (MODE == 9) { x0 = __builtin_amdgcn_sinf(x0); x1 = __builtin_amdgcn_sinf(x1); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (MODE == 10) {   // accumulator in AGPRs + LDS ring into VGPRs
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "a"(A[i]), "v"(Br[i % 4]));
+                Br[i % 4] = __builtin_bit_cast(bf16x8, base[i * 64]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (MODE == 11) {   // A in VGPRs, B ring loaded into AGPRs, acc in VGPRs
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(A[i]), "a"(Br[i % 4]));
+                Br[i % 4] = __builtin_bit_cast(bf16x8, base[i * 64]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (MODE == 12) {   // ds_read only every second step (two MFMAs per B fragment)
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(A[i]), "v"(Br[(i >> 1) % 4]));
+                if (i & 1) Br[(i >> 1) % 4] = __builtin_bit_cast(bf16x8, base[i * 64]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (MODE == 13) {   // ds_read_b64 x2 instead of b128
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(A[i]), "v"(Br[i % 4]));
+                typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                typedef __attribute__((address_space(3))) u32x2 lq2;
+                lq2* b2 = (lq2*)lds + lane;
+                u32x2 lo = b2[i * 128], hi = b2[i * 128 + 64];
+                Br[i % 4] = __builtin_bit_cast(bf16x8, (u32x4){ lo.x, lo.y, hi.x, hi.y });
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (MODE == 5) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i], B[i & 3], acc, 0, 0, 0);
+            if (MODE == 6) {                 // builtin + LDS ring
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i], B[i & 3], acc, 0, 0, 0);
+                B[i & 3] = __builtin_bit_cast(bf16x8, base[((i + it) & 15) * 64]);
+            }
+        }
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (lane == 0) out[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+    float s = x0 + x1;
+    for (int i = 0; i < 16; ++i) s += acc[i];
+    sink[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+template <int MODE> void run(const char* name, uint4* w, unsigned long long* out, float* sink) {
+    for (int r = 0; r < 3; ++r) hipLaunchKernelGGL(k<MODE>, dim3(256), dim3(256), 0, 0, w, out, sink);
+    hipDeviceSynchronize();
+    std::vector<unsigned long long> h(1024);
+    hipMemcpy(h.data(), out, 1024 * 8, hipMemcpyDeviceToHost);
+    std::sort(h.begin(), h.end());
+    printf("%-46s median %.2f cycles per MFMA (min %.2f, max %.2f)\n", name, h[512] / 1024.0, h[0] / 1024.0, h[1023] / 1024.0);
+}
+
+int main() {
+    uint4* w; unsigned long long* out; float* sink;
+    hipMalloc(&w, 20 * 64 * 16); hipMalloc(&out, 1024 * 8); hipMalloc(&sink, 256 * 256 * 4);
+    std::vector<unsigned> hw(20 * 64 * 4);
+    for (size_t i = 0; i < hw.size(); ++i) hw[i] = 0x3f803f80u ^ (unsigned)(i * 2654435761u >> 20);
+    hipMemcpy(w, hw.data(), hw.size() * 4, hipMemcpyHostToDevice);
+    run<0>("asm A=agpr B=vgpr C/D=vgpr", w, out, sink);
+    run<1>("asm A=agpr B=vgpr C/D=agpr", w, out, sink);
+    run<2>("asm A=vgpr B=vgpr C/D=vgpr", w, out, sink);
+    run<3>("asm A=agpr C/D=vgpr + ds_read_b128 per step", w, out, sink);
+    run<7>("asm + ds_read_b128 imm offset, ring 4", w, out, sink);
+    run<8>("asm + ds_read_b128 imm offset, ring 8", w, out, sink);
+    run<9>("asm + ds_read imm, ring 4 + 2 v_sin per step", w, out, sink);
+    run<10>("asm C/D=agpr + ds_read imm ring 4", w, out, sink);
+    run<11>("asm A=vgpr, B ring in AGPRs + ds_read", w, out, sink);
+    run<12>("asm + ds_read every 2nd MFMA", w, out, sink);
+    run<13>("asm + 2 x ds_read_b64 per step", w, out, sink);
+    run<5>("builtin", w, out, sink);
+    run<6>("builtin + ds_read_b128 per step", w, out, sink);
+    return 0;
+}
