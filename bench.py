@@ -58,7 +58,7 @@ def parse():
     ap.add_argument("--image", type=int, default=0, help="image side; 0 = 1024 at one GPU (C3), 2048 at N > 1 (C4)")
     ap.add_argument("--march-steps", type=int, default=512)
     ap.add_argument("--math", default="strict", choices=["strict", "fast"])
-    ap.add_argument("--layout", default="auto", choices=["auto", "vg", "quad", "brick", "linear"],
+    ap.add_argument("--layout", default="auto", choices=["auto", "vg", "vga", "quad", "brick", "linear"],
                     help="HBM layout of the volume; auto = vg (value+gradient float4 bricks) when shading, quad otherwise")
     ap.add_argument("--no-shade", action="store_true", help="reference-only K1 (no gradient shading)")
     ap.add_argument("--alpha", type=float, default=16.0, help="intensityAlpha (16 = dense preset: ERT fires)")

@@ -73,7 +73,13 @@ typedef enum MrirtLayout {
      *        QUAD = (v[x,y], v[x,y+1], v[x+1,y], v[x+1,y+1]) (indices clamped): an unshaded
      *                trilinear sample is 2 dwordx4 gathers instead of 8 dword gathers.          */
     MRIRT_LAYOUT_VG = 2,
-    MRIRT_LAYOUT_QUAD = 3
+    MRIRT_LAYOUT_QUAD = 3,
+    /* VGA = the VG voxels stored three times, in 128-B bricks one voxel thick along x, y or z (1x4x2 / 4x1x2 /
+     *       4x2x1 voxels).  A ray packet's samples of one march step lie on a sheet parallel to the face the rays
+     *       entered through; the kernel reads the copy whose bricks are flat in that direction (chosen per packet),
+     *       so a gather touches about half the cache lines of the 2x2x2 bricks.  Same bits as VG; 3x the memory
+     *       (6 GiB for a 512^3 channel: sized for 288 GB of HBM).  mrirt_vga_elems / mrirt_build_vec4_grid.        */
+    MRIRT_LAYOUT_VGA = 4
 } MrirtLayout;
 
 typedef enum MrirtMath {
@@ -166,7 +172,9 @@ int mrirt_brick_grid(const void* linear, void* bricked, const uint32_t dims[3], 
 int mrirt_unbrick_grid(const void* bricked, void* linear, const uint32_t dims[3], uint32_t elem_bytes, void* stream);
 /* Number of float4 ELEMENTS a VG / QUAD grid of `dims` occupies. */
 int64_t mrirt_vec4_elems(const uint32_t dims[3]);
-/* linear fp32 (x fastest) -> VG or QUAD float4 grid (layout = MRIRT_LAYOUT_VG / _QUAD). */
+/* Number of float4 ELEMENTS the three copies of a VGA grid of `dims` occupy together. */
+int64_t mrirt_vga_elems(const uint32_t dims[3]);
+/* linear fp32 (x fastest) -> VG, QUAD or VGA float4 grid (layout = MRIRT_LAYOUT_VG / _QUAD / _VGA). */
 int mrirt_build_vec4_grid(const float* linear, void* vec4_grid, const uint32_t dims[3], uint32_t layout, void* stream);
 /* BC4 / RGTC1-unorm slices (8-byte blocks, [depth][ceil(h/4)][ceil(w/4)], device, 8-byte aligned) -> u8 voxels
  * [depth][height][width]: the decode scripts/volumeRendering/app.py:200-250 does on the host. */

@@ -24,297 +24,9 @@
 // Template axes: STRICT (bit-faithful to the oracle / FAST: FMA + hardware exp2, rcp), LAYOUT
 // (0 linear, 1 4x4x2 fp32 bricks, 2 VG, 3 QUAD), SHADE (lattice-gradient Blinn-Phong extension); the
 // pipelined kernel adds NCH (modalities), GAMMA1, LABELS, SKIP (exact empty-space skipping).
-#include "mrirt_host.h"
+#include "brats_device.h"
 
 namespace mrirt {
-
-constexpr uint32_t kMaxStepsPerRay = 1u << 20;   // prepare(): stepSize may not cut the box diagonal finer
-
-struct K1Args {
-    Camera cam;
-    PixelMap map;
-    GridDims grid;
-    LabelAddr lab;
-    float bmin[3], bmax[3];
-    UDiv vox[3];             // voxelSize per axis (pIdx = (p - bmin) / voxelSize)
-    UDiv wsum;               // sum of the enabled volWeight, accumulated in slot order
-    UDiv wwDiv;              // ww
-    float halfInvVoxel[3];   // 0.5f / voxelSize      (gradient to world units)
-    float hiLin[3];          // float(dims) - 1.001f   (sampleLinear clamp)
-    float hiLab[3];          // float(dims) - 1.0f     (sampleLabel clamp)
-    float stepSize, nearT, farT;
-    float bg[3];
-    uint32_t enabled[4];
-    float weight[4];
-    float tfLo;              // wl - ww*0.5
-    float intensityAlpha, gamma;
-    uint32_t showSeg, showPred;
-    float lut[8][4];
-    float segAlpha[8], predAlpha[8];   // the overlays' per-label opacities (exp of a launch constant: computed on the host)
-    float ka, kd, ks, gradEps, ert;
-    uint32_t specPow2;
-    uint32_t half;           // 1: rgba16_float output
-    uint32_t nch, chan[4];   // the enabled modalities, compacted in ascending order (pipelined kernel)
-    const void* vol[4];
-    const uint32_t* labels;
-    const uint32_t* preds;
-    const int16_t* classStream;   // C5: prediction label of sample k of ray p at classStream[rayOffsets[p] + k]
-    const int64_t* rayOffsets;
-    const uint32_t* skipMask;     // exact empty-space skipping: bit per 8^3 macro cell, 1 = contributes nothing
-    uint32_t mX, mXY;             // macro cells per row / per slice
-    void* out;
-    uint64_t* stats;
-    ExpConsts ec;                 // fp64 constants of the strict exp, SGPR-resident
-    uint32_t expSmall;            // intensityAlpha * stepSize <= 1/8: the intensity exp needs no range reduction
-};
-
-template <bool STRICT>
-__device__ __forceinline__ float trilerp(float c000, float c100, float c010, float c110,
-                                         float c001, float c101, float c011, float c111,
-                                         float fx, float fy, float fz) {
-    using Mm = M<STRICT>;   // nesting order of sampleLinear, brats_rt.slang:74-75
-    return Mm::lerp(Mm::lerp(Mm::lerp(c000, c100, fx), Mm::lerp(c010, c110, fx), fy),
-                    Mm::lerp(Mm::lerp(c001, c101, fx), Mm::lerp(c011, c111, fx), fy), fz);
-}
-
-// ---------------------------------------------------------------------------------------
-// One sample's position in index space: sampleLinear's clamp / floor / fract (shared by all
-// modalities) plus the unclamped pIdx the label fetch rounds.
-// ---------------------------------------------------------------------------------------
-struct Cell {
-    float q[3];              // pIdx
-    float fx, fy, fz;
-    uint32_t ix, iy, iz;
-};
-
-template <bool STRICT>
-__device__ __forceinline__ void locate(const K1Args& a, const float ro[3], const float rd[3], float t, Cell& c) {
-    using Mm = M<STRICT>;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const float p = Mm::mad(t, rd[k], ro[k]);                    // o + t*d (the sum commutes)
-        c.q[k] = Mm::divu(p - a.bmin[k], a.vox[k]);                  // brats_rt.slang:119-120
-    }
-    const float cx = clampf(c.q[0], 0.0f, a.hiLin[0]);               // :62-64
-    const float cy = clampf(c.q[1], 0.0f, a.hiLin[1]);
-    const float cz = clampf(c.q[2], 0.0f, a.hiLin[2]);
-    const float flx = floorf(cx), fly = floorf(cy), flz = floorf(cz);
-    c.ix = (uint32_t)flx; c.iy = (uint32_t)fly; c.iz = (uint32_t)flz;
-    c.fx = cx - flx; c.fy = cy - fly; c.fz = cz - flz;
-}
-
-// ---------------------------------------------------------------------------------------
-// Taps: the gathers of one modality at one cell (issue), and their blend (eval).  Splitting the
-// two lets the pipelined kernel keep a whole step of gathers in flight.
-// ---------------------------------------------------------------------------------------
-template <int LAYOUT, bool SHADE> struct Taps;
-
-template <bool SHADE> struct Taps<2, SHADE> {        // VG: 8 x (v, dx, dy, dz)
-    float4 c[8];
-    template <bool WIDE>
-    __device__ __forceinline__ void issue(const void* __restrict__ vbuf, const GridDims& gd, const Cell& s) {
-        const CellOffsets k = vec4_cell(gd, s.ix, s.iy, s.iz);
-        constexpr bool w = WIDE;
-        const uint32_t o10 = k.o + k.dx, o01 = k.o + k.dy, o11 = o10 + k.dy;
-        c[0] = load_vec4<w>(vbuf, k.o);        c[1] = load_vec4<w>(vbuf, o10);
-        c[2] = load_vec4<w>(vbuf, o01);        c[3] = load_vec4<w>(vbuf, o11);
-        c[4] = load_vec4<w>(vbuf, k.o + k.dz); c[5] = load_vec4<w>(vbuf, o10 + k.dz);
-        c[6] = load_vec4<w>(vbuf, o01 + k.dz); c[7] = load_vec4<w>(vbuf, o11 + k.dz);
-    }
-    template <bool STRICT>
-    __device__ __forceinline__ void eval(const Cell& s, float& v, float g[3]) const {
-        if constexpr (SHADE) {
-            // (v, dx) and (dy, dz) blend as register pairs: 42 packed instructions instead of 84
-#define MRIRT_LO(i) f32x2{ c[i].x, c[i].y }
-#define MRIRT_HI(i) f32x2{ c[i].z, c[i].w }
-            const f32x2 lo = trilerp2<STRICT>(MRIRT_LO(0), MRIRT_LO(1), MRIRT_LO(2), MRIRT_LO(3),
-                                              MRIRT_LO(4), MRIRT_LO(5), MRIRT_LO(6), MRIRT_LO(7), s.fx, s.fy, s.fz);
-            const f32x2 hi = trilerp2<STRICT>(MRIRT_HI(0), MRIRT_HI(1), MRIRT_HI(2), MRIRT_HI(3),
-                                              MRIRT_HI(4), MRIRT_HI(5), MRIRT_HI(6), MRIRT_HI(7), s.fx, s.fy, s.fz);
-#undef MRIRT_LO
-#undef MRIRT_HI
-            v = lo.x; g[0] = lo.y; g[1] = hi.x; g[2] = hi.y;
-        } else {
-            v = trilerp<STRICT>(c[0].x, c[1].x, c[2].x, c[3].x, c[4].x, c[5].x, c[6].x, c[7].x, s.fx, s.fy, s.fz);
-        }
-    }
-};
-
-template <> struct Taps<3, false> {                  // QUAD: the z and z+1 xy-quads (x0y0, x0y1, x1y0, x1y1)
-    float4 q0, q1;
-    template <bool WIDE>
-    __device__ __forceinline__ void issue(const void* __restrict__ vbuf, const GridDims& gd, const Cell& s) {
-        const CellOffsets k = vec4_cell(gd, s.ix, s.iy, s.iz);
-        q0 = load_vec4<WIDE>(vbuf, k.o);
-        q1 = load_vec4<WIDE>(vbuf, k.o + k.dz);
-    }
-    template <bool STRICT>
-    __device__ __forceinline__ void eval(const Cell& s, float& v, float*) const {
-        // q = (c00, c01, c10, c11) [x then y]: the x blend of the y0 and y1 rows is one packed lerp per plane
-        using Mm = M<STRICT>;
-        const f32x2 r0 = lerp2<STRICT>(f32x2{ q0.x, q0.y }, f32x2{ q0.z, q0.w }, s.fx);
-        const f32x2 r1 = lerp2<STRICT>(f32x2{ q1.x, q1.y }, f32x2{ q1.z, q1.w }, s.fx);
-        v = Mm::lerp(Mm::lerp(r0.x, r0.y, s.fy), Mm::lerp(r1.x, r1.y, s.fy), s.fz);
-    }
-};
-
-template <int LAYOUT, bool SHADE> struct TapsScalar {        // LINEAR / BRICK fp32 grids
-    float c[8];
-    float n[SHADE ? 24 : 1];                                 // +-1 neighbours of the 8 corners per axis
-    template <bool WIDE>
-    __device__ __forceinline__ void issue(const void* __restrict__ vbuf, const GridDims& gd, const Cell& s) {
-        using A = Addr<LAYOUT>;
-        const float* __restrict__ buf = static_cast<const float*>(vbuf);
-        const uint32_t x0 = A::ox(gd, s.ix), x1 = A::ox(gd, s.ix + 1);
-        const uint32_t y0 = A::oy(gd, s.iy), y1 = A::oy(gd, s.iy + 1);
-        const uint32_t z0 = A::oz(gd, s.iz), z1 = A::oz(gd, s.iz + 1);
-        // core 2x2x2 (sampleLinear, brats_rt.slang:69-72)
-        c[0] = buf[x0 + y0 + z0]; c[1] = buf[x1 + y0 + z0]; c[2] = buf[x0 + y1 + z0]; c[3] = buf[x1 + y1 + z0];
-        c[4] = buf[x0 + y0 + z1]; c[5] = buf[x1 + y0 + z1]; c[6] = buf[x0 + y1 + z1]; c[7] = buf[x1 + y1 + z1];
-        if constexpr (SHADE) {
-            const uint32_t xm = A::ox(gd, s.ix > 0 ? s.ix - 1 : 0), xp = A::ox(gd, min(s.ix + 2, gd.X - 1));
-            const uint32_t ym = A::oy(gd, s.iy > 0 ? s.iy - 1 : 0), yp = A::oy(gd, min(s.iy + 2, gd.Y - 1));
-            const uint32_t zm = A::oz(gd, s.iz > 0 ? s.iz - 1 : 0), zp = A::oz(gd, min(s.iz + 2, gd.Z - 1));
-            n[0] = buf[xm + y0 + z0]; n[1] = buf[xp + y0 + z0]; n[2] = buf[xm + y1 + z0]; n[3] = buf[xp + y1 + z0];
-            n[4] = buf[xm + y0 + z1]; n[5] = buf[xp + y0 + z1]; n[6] = buf[xm + y1 + z1]; n[7] = buf[xp + y1 + z1];
-            n[8] = buf[x0 + ym + z0]; n[9] = buf[x1 + ym + z0]; n[10] = buf[x0 + yp + z0]; n[11] = buf[x1 + yp + z0];
-            n[12] = buf[x0 + ym + z1]; n[13] = buf[x1 + ym + z1]; n[14] = buf[x0 + yp + z1]; n[15] = buf[x1 + yp + z1];
-            n[16] = buf[x0 + y0 + zm]; n[17] = buf[x1 + y0 + zm]; n[18] = buf[x0 + y1 + zm]; n[19] = buf[x1 + y1 + zm];
-            n[20] = buf[x0 + y0 + zp]; n[21] = buf[x1 + y0 + zp]; n[22] = buf[x0 + y1 + zp]; n[23] = buf[x1 + y1 + zp];
-        }
-    }
-    template <bool STRICT>
-    __device__ __forceinline__ void eval(const Cell& s, float& v, float g[3]) const {
-        v = trilerp<STRICT>(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], s.fx, s.fy, s.fz);
-        if constexpr (SHADE) {
-            // corner (0,dy,dz): v[i+1]-v[i-1]; corner (1,dy,dz): v[i+2]-v[i]; likewise in y and z
-            g[0] = trilerp<STRICT>(c[1] - n[0], n[1] - c[0], c[3] - n[2], n[3] - c[2],
-                                   c[5] - n[4], n[5] - c[4], c[7] - n[6], n[7] - c[6], s.fx, s.fy, s.fz);
-            g[1] = trilerp<STRICT>(c[2] - n[8], c[3] - n[9], n[10] - c[0], n[11] - c[1],
-                                   c[6] - n[12], c[7] - n[13], n[14] - c[4], n[15] - c[5], s.fx, s.fy, s.fz);
-            g[2] = trilerp<STRICT>(c[4] - n[16], c[5] - n[17], c[6] - n[18], c[7] - n[19],
-                                   n[20] - c[0], n[21] - c[1], n[22] - c[2], n[23] - c[3], s.fx, s.fy, s.fz);
-        }
-    }
-};
-template <bool SHADE> struct Taps<0, SHADE> : TapsScalar<0, SHADE> {};
-template <bool SHADE> struct Taps<1, SHADE> : TapsScalar<1, SHADE> {};
-
-__device__ __forceinline__ uint32_t sample_label(const uint32_t* __restrict__ buf, const LabelAddr& la,
-                                                 const float q[3], const float hi[3]) {
-    // sampleLabel, brats_rt.slang:78-83; roundf = half away from zero (Metal round)
-    const uint32_t ix = (uint32_t)roundf(clampf(q[0], 0.0f, hi[0]));
-    const uint32_t iy = (uint32_t)roundf(clampf(q[1], 0.0f, hi[1]));
-    const uint32_t iz = (uint32_t)roundf(clampf(q[2], 0.0f, hi[2]));
-    return buf[la.off(ix, iy, iz)];
-}
-
-// ---------------------------------------------------------------------------------------
-// Everything after the blended intensity v (and weighted gradient g) is known:
-// transfer function, emission-absorption step, label overlays.  brats_rt.slang:130-162.
-// ---------------------------------------------------------------------------------------
-struct RayState { float C0, C1, C2, T; uint32_t nLive, nShaded; };
-
-// the two nearest-label gathers of a sample (issued with the intensity gathers, consumed in composite)
-struct Labels { uint32_t seg, pred; };
-__device__ __forceinline__ void fetch_labels(const K1Args& a, const Cell& s, Labels& l, int64_t streamRow = 0) {
-    l.seg = a.showSeg != 0 ? sample_label(a.labels, a.lab, s.q, a.hiLab) : 0u;      // :144
-    if (a.showPred == 0) l.pred = 0u;
-    else if (a.classStream != nullptr) l.pred = (uint32_t)(uint16_t)a.classStream[streamRow];   // C5
-    else l.pred = sample_label(a.preds, a.lab, s.q, a.hiLab);                       // :155
-}
-
-// GAMMA1: gamma == 1 (the viewer's constant, brats_viewer.py:422), where pow(val, 1) == val exactly;
-// compiling the fp64 pow out of the hot kernels frees the registers its temporaries would claim.
-template <bool STRICT, bool SHADE, bool GAMMA1 = false, bool LABELS = true>
-__device__ __forceinline__ void composite(const K1Args& a, const float rd[3], const Labels& lb, float v, const float g[3],
-                                          RayState& r) {
-    using Mm = M<STRICT>;
-    // wSum (brats_rt.slang:123-130) is the same for every sample: summed on the host
-    if (a.wsum.d > 0.0f && a.wsum.d != 1.0f) v = Mm::divu(v, a.wsum);      // x / 1 == x: skip the three instructions
-    float val = satf(Mm::divu(v - a.tfLo, a.wwDiv));                 // :132
-    if constexpr (!GAMMA1) val = Mm::pow(val, a.gamma);              // :133
-    ++r.nLive;
-    if (val > 0.0f) {
-        const float ex = -(val * a.intensityAlpha) * a.stepSize;
-        float e;
-        // constants: SGPR operands in the lean kernels; literals where the shading / overlay state already fills
-        // the SGPR file (the 32 extra SGPRs spill there: measured +6 % on the 4-modality + overlay frame)
-        constexpr bool LIT = SHADE || LABELS;
-        if (a.expSmall) e = LIT ? Mm::exp_small_lit(ex) : Mm::exp_small(ex, a.ec);        // uniform: |ex| <= 1/8 for every sample
-        else            e = LIT ? Mm::exp_lit(ex) : Mm::exp(ex, a.ec);
-        const float alpha = 1.0f - e;
-        float emis = val;
-        if constexpr (SHADE) {
-            // headlight Blinn-Phong on the lattice gradient (build-defined extension):
-            // world gradient = index-space difference * 0.5/voxelSize; n.l = |g.d| / |g|
-            const float gx = g[0] * a.halfInvVoxel[0], gy = g[1] * a.halfInvVoxel[1], gz = g[2] * a.halfInvVoxel[2];
-            const float len2 = dot3(gx, gy, gz, gx, gy, gz);
-            const float glen = STRICT ? sqrtf(len2) : __builtin_amdgcn_sqrtf(len2);
-            float shade = a.ka + a.kd;
-            if (glen > a.gradEps) {
-                const float gd = fabsf(dot3(gx, gy, gz, rd[0], rd[1], rd[2]));
-                const float ndl = fminf(STRICT ? gd / glen : gd * __builtin_amdgcn_rcpf(glen), 1.0f);
-                float spec = ndl;
-                for (uint32_t k = 0; k < a.specPow2; ++k) spec = spec * spec;
-                shade = (a.ka + a.kd * ndl) + a.ks * spec;
-            }
-            emis = val * shade;
-            ++r.nShaded;
-        }
-        const float c = (alpha * r.T) * emis;
-        r.C0 += c; r.C1 += c; r.C2 += c;
-        r.T *= (1.0f - alpha);
-    }
-    if (LABELS && a.showSeg != 0) {                                  // :143-151
-        const uint32_t l = lb.seg;
-        if (l > 0 && l < 8) {
-            const float alpha = a.segAlpha[l];                           // 1 - exp(-lut[l].w * dt): seven values per launch, host-made
-            const float at = alpha * r.T;
-            r.C0 += at * a.lut[l][0]; r.C1 += at * a.lut[l][1]; r.C2 += at * a.lut[l][2];
-            r.T *= (1.0f - alpha);
-        }
-    }
-    if (LABELS && a.showPred != 0) {                                 // :154-162
-        const uint32_t l = lb.pred;
-        if (l > 0 && l < 8) {
-            const float alpha = a.predAlpha[l];                          // 1 - exp(-lut[l].w * dt * 1.5)
-            const float at = alpha * r.T;
-            r.C0 += at * a.lut[l][0]; r.C1 += at * a.lut[l][1]; r.C2 += at * a.lut[l][2];
-            r.T *= (1.0f - alpha);
-        }
-    }
-}
-
-// ray generation + slab clip (brats_rt.slang:91-109); returns whether the ray marches
-__device__ __forceinline__ bool setup_ray(const K1Args& a, uint32_t px, uint32_t py, float ro[3], float rd[3],
-                                          float& t0, float& t1) {
-    primary_ray(a.cam, px, py, ro, rd);
-    float tmin = -INFINITY, tmax = INFINITY;   // rcp uses the nudged direction, marching the true one
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const float d = fabsf(rd[k]) < 1e-6f ? 1e-6f : rd[k];
-        const float rcp = 1.0f / d;
-        const float ta = (a.bmin[k] - ro[k]) * rcp, tb = (a.bmax[k] - ro[k]) * rcp;
-        tmin = fmaxf(tmin, fminf(ta, tb));
-        tmax = fminf(tmax, fmaxf(ta, tb));
-    }
-    const bool hit = tmax >= fmaxf(tmin, 0.0f);
-    t0 = fmaxf(tmin, fmaxf(0.0f, a.nearT));
-    t1 = fminf(tmax, a.farT > 0.0f ? a.farT : tmax);
-    return hit && !(t1 <= t0);
-}
-
-__device__ __forceinline__ void finish(const K1Args& a, int kind, int64_t oidx, const RayState& r) {
-    if (kind != 0) {
-        if (a.half) store_rgba<true>(a.out, oidx, r.C0, r.C1, r.C2, 1.0f);
-        else        store_rgba<false>(a.out, oidx, r.C0, r.C1, r.C2, 1.0f);
-    }
-    if (a.stats != nullptr) {
-        wave_count_add(a.stats + 0, r.nLive);
-        wave_count_add(a.stats + 1, r.nShaded);
-    }
-}
 
 // ---------------------------------------------------------------------------------------
 // General kernel: any subset of the four modalities, gathers issued and consumed per step.
@@ -326,34 +38,36 @@ __global__ __launch_bounds__(256) void brats_march_kernel(const K1Args a) {
     int64_t oidx;
     const int kind = map_pixel(a.map, px, py, oidx);
     RayState r = { a.bg[0], a.bg[1], a.bg[2], 1.0f, 0u, 0u };
-    if (kind == 1) {
-        float ro[3], rd[3], t0, t1;
-        if (setup_ray(a, px, py, ro, rd, t0, t1)) {
-            float t = t0;
-            const int64_t streamBase = a.classStream != nullptr ? a.rayOffsets[(int64_t)py * a.map.width + px] : 0;
-            while (t < t1 && r.T > a.ert) {
-                Cell s;
-                locate<STRICT>(a, ro, rd, t, s);
-                float v = 0.0f, g[3] = { 0.0f, 0.0f, 0.0f };
+    float ro[3] = { 0.0f, 0.0f, 0.0f }, rd[3] = { 0.0f, 0.0f, 1.0f }, t0 = 0.0f, t1 = 0.0f;
+    const bool marches = kind == 1 && setup_ray(a, px, py, ro, rd, t0, t1);
+    WaveGrid<LAYOUT> wg;
+    if constexpr (LAYOUT == 4) wg.f = a.vga.ax[vga_pick_axis(a, ro, rd, marches)];      // every lane votes: outside the branch
+    else wg.g = &a.grid;
+    if (marches) {
+        float t = t0;
+        const int64_t streamBase = a.classStream != nullptr ? a.rayOffsets[(int64_t)py * a.map.width + px] : 0;
+        while (t < t1 && r.T > a.ert) {
+            Cell s;
+            locate<STRICT>(a, ro, rd, t, s);
+            float v = 0.0f, g[3] = { 0.0f, 0.0f, 0.0f };
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    if (a.enabled[m] != 0) {
-                        Taps<LAYOUT, SHADE> taps;
-                        float sv, gm[3];
-                        taps.template issue<true>(a.vol[m], a.grid, s);
-                        taps.template eval<STRICT>(s, sv, gm);
-                        v = Mm::mad(sv, a.weight[m], v);
-                        if constexpr (SHADE) {
+            for (int m = 0; m < 4; ++m) {
+                if (a.enabled[m] != 0) {
+                    Taps<LAYOUT, SHADE> taps;
+                    float sv, gm[3];
+                    taps.template issue<true>(wg.base(a.vol[m]), wg.dims(), s);
+                    taps.template eval<STRICT>(s, sv, gm);
+                    v = Mm::mad(sv, a.weight[m], v);
+                    if constexpr (SHADE) {
 #pragma unroll
-                            for (int k = 0; k < 3; ++k) g[k] = Mm::mad(gm[k], a.weight[m], g[k]);
-                        }
+                        for (int k = 0; k < 3; ++k) g[k] = Mm::mad(gm[k], a.weight[m], g[k]);
                     }
                 }
-                Labels lb;
-                fetch_labels(a, s, lb, streamBase + r.nLive);       // nLive == index of this step along the ray
-                composite<STRICT, SHADE>(a, rd, lb, v, g, r);
-                t += a.stepSize;
             }
+            Labels lb;
+            fetch_labels(a, s, lb, streamBase + r.nLive);       // nLive == index of this step along the ray
+            composite<STRICT, SHADE>(a, rd, lb, v, g, r);
+            t += a.stepSize;
         }
     }
     finish(a, kind, oidx, r);
@@ -394,10 +108,10 @@ struct Stage {
     }
     // streamRow / streamValid: C5's class stream (one class per sample of the ray); the fetch of step k+1 is
     // speculative, so it is made only when that sample exists (t_next < t1)
-    __device__ __forceinline__ void issue(const K1Args& a, int64_t streamRow = 0, bool streamValid = true) {
+    __device__ __forceinline__ void issue(const K1Args& a, const WaveGrid<LAYOUT>& wg, int64_t streamRow = 0, bool streamValid = true) {
         if (SKIP && empty) return;
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) taps[c].template issue<false>(a.vol[a.chan[c]], a.grid, s);   // grid < 4 GiB (launch())
+        for (int c = 0; c < NCH; ++c) taps[c].template issue<false>(wg.base(a.vol[a.chan[c]]), wg.dims(), s);   // grid (copy) < 4 GiB (launch())
         if constexpr (LABELS) {
             if (a.classStream != nullptr && !streamValid) { lb.seg = a.showSeg != 0 ? sample_label(a.labels, a.lab, s.q, a.hiLab) : 0u; lb.pred = 0u; }
             else fetch_labels(a, s, lb, streamRow);
@@ -441,34 +155,36 @@ __global__ __launch_bounds__(256, (LABELS || SKIP) ? 3 : 4) void brats_march_pip
     int64_t oidx;
     const int kind = map_pixel(a.map, px, py, oidx);
     RayState r = { a.bg[0], a.bg[1], a.bg[2], 1.0f, 0u, 0u };
-    if (kind == 1) {
-        float ro[3], rd[3], t0, t1;
-        if (setup_ray(a, px, py, ro, rd, t0, t1) && t0 < t1 && 1.0f > a.ert) {   // the while-condition at entry
-            float t = t0;
-            Stage<LAYOUT, SHADE, NCH, LABELS, SKIP> A, B;
-            SkipCursor cur = { 0xffffffffu, false };
-            int64_t row = 0;                                             // C5: next row of this ray in the class stream
-            if constexpr (LABELS) { if (a.classStream != nullptr) row = a.rayOffsets[(int64_t)py * a.map.width + px]; }
-            locate<STRICT>(a, ro, rd, t, A.s);
+    float ro[3] = { 0.0f, 0.0f, 0.0f }, rd[3] = { 0.0f, 0.0f, 1.0f }, t0 = 0.0f, t1 = 0.0f;
+    const bool marches = kind == 1 && setup_ray(a, px, py, ro, rd, t0, t1) && t0 < t1 && 1.0f > a.ert;   // the while-condition at entry
+    WaveGrid<LAYOUT> wg;
+    if constexpr (LAYOUT == 4) wg.f = a.vga.ax[vga_pick_axis(a, ro, rd, marches)];      // every lane votes: outside the branch
+    else wg.g = &a.grid;
+    if (marches) {
+        float t = t0;
+        Stage<LAYOUT, SHADE, NCH, LABELS, SKIP> A, B;
+        SkipCursor cur = { 0xffffffffu, false };
+        int64_t row = 0;                                             // C5: next row of this ray in the class stream
+        if constexpr (LABELS) { if (a.classStream != nullptr) row = a.rayOffsets[(int64_t)py * a.map.width + px]; }
+        locate<STRICT>(a, ro, rd, t, A.s);
+        A.classify(a, cur);
+        A.issue(a, wg, row++, true);
+        while (true) {
+            // invariant: stage A holds the sample at t, and (t < t1 && T > ert) holds
+            float tn = t + a.stepSize;
+            locate<STRICT>(a, ro, rd, tn, B.s);
+            B.classify(a, cur);
+            B.issue(a, wg, row++, tn < t1);                       // speculative next step
+            A.template consume<STRICT, GAMMA1>(a, rd, r);
+            t = tn;
+            if (!(t < t1 && r.T > a.ert)) break;
+            tn = t + a.stepSize;
+            locate<STRICT>(a, ro, rd, tn, A.s);
             A.classify(a, cur);
-            A.issue(a, row++, true);
-            while (true) {
-                // invariant: stage A holds the sample at t, and (t < t1 && T > ert) holds
-                float tn = t + a.stepSize;
-                locate<STRICT>(a, ro, rd, tn, B.s);
-                B.classify(a, cur);
-                B.issue(a, row++, tn < t1);                           // speculative next step
-                A.template consume<STRICT, GAMMA1>(a, rd, r);
-                t = tn;
-                if (!(t < t1 && r.T > a.ert)) break;
-                tn = t + a.stepSize;
-                locate<STRICT>(a, ro, rd, tn, A.s);
-                A.classify(a, cur);
-                A.issue(a, row++, tn < t1);
-                B.template consume<STRICT, GAMMA1>(a, rd, r);
-                t = tn;
-                if (!(t < t1 && r.T > a.ert)) break;
-            }
+            A.issue(a, wg, row++, tn < t1);
+            B.template consume<STRICT, GAMMA1>(a, rd, r);
+            t = tn;
+            if (!(t < t1 && r.T > a.ert)) break;
         }
     }
     finish(a, kind, oidx, r);
@@ -502,6 +218,9 @@ static int launch(const K1Args& a, bool pipe, hipStream_t s) {
     if constexpr (LAYOUT == 2) {                      // VG: 8 float4 per modality per stage -> one modality
         if (pipe && a.nch == 1 && !a.grid.wide) return launch_pipe<STRICT, 2, SHADE, 1>(a, s);
     }
+    if constexpr (LAYOUT == 4) {                      // VGA: as VG; every copy is < 4 GiB by construction (prepare())
+        if (pipe && a.nch == 1) return launch_pipe<STRICT, 4, SHADE, 1>(a, s);
+    }
     if constexpr (LAYOUT == 3) {                      // QUAD: 2 float4 per modality per stage -> up to four
         if (pipe && !a.grid.wide) {
             switch (a.nch) {
@@ -526,6 +245,7 @@ static int launch_layout(const K1Args& a, uint32_t layout, bool shade, bool pipe
         case MRIRT_LAYOUT_BRICK:  return shade ? launch<STRICT, 1, true>(a, false, s) : launch<STRICT, 1, false>(a, false, s);
         case MRIRT_LAYOUT_VG:     return shade ? launch<STRICT, 2, true>(a, pipe, s) : launch<STRICT, 2, false>(a, pipe, s);
         case MRIRT_LAYOUT_QUAD:   return shade ? (int)MRIRT_ERR_LAYOUT : launch<STRICT, 3, false>(a, pipe, s);
+        case MRIRT_LAYOUT_VGA:    return shade ? launch<STRICT, 4, true>(a, pipe, s) : launch<STRICT, 4, false>(a, pipe, s);
         default: return MRIRT_ERR_LAYOUT;
     }
 }
@@ -562,7 +282,7 @@ __device__ __forceinline__ void emit_row(const K1Args& a, const EmitArgs& e, con
     float z[4];
     Taps<LAYOUT, false> taps[4];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) taps[m].template issue<true>(a.vol[m], a.grid, s);      // all gathers in flight first
+    for (int m = 0; m < 4; ++m) taps[m].template issue<true>(a.vol[m], a.grid, s);      // all gathers in flight first (layouts 0..3)
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         float v;
@@ -712,8 +432,10 @@ static int prepare(const MrirtBratsParams* p, const MrirtRenderExt* ext, const v
     const uint32_t math = ext ? ext->math : (uint32_t)MRIRT_MATH_STRICT;
     const uint32_t fmt = ext ? ext->outFormat : (uint32_t)MRIRT_OUT_RGBA32F;
     const uint32_t variant = ext ? ext->kernelVariant : 0u;
-    if (layout > MRIRT_LAYOUT_QUAD || labLayout > MRIRT_LAYOUT_BRICK || math > MRIRT_MATH_FAST || fmt > MRIRT_OUT_RGBA16F)
+    if (layout > MRIRT_LAYOUT_VGA || labLayout > MRIRT_LAYOUT_BRICK || math > MRIRT_MATH_FAST || fmt > MRIRT_OUT_RGBA16F)
         return MRIRT_ERR_LAYOUT;
+    if (layout == MRIRT_LAYOUT_VGA)
+        for (int c = 0; c < 3; ++c) if (vga_copy_elems(p->dims, c) >= (1ull << 28)) return MRIRT_ERR_DIMS;   // 32-bit byte offsets per copy
     if (mrirt_brick_elems(p->dims) >= (int64_t)1 << 32 || mrirt_vec4_elems(p->dims) >= (int64_t)1 << 32)
         return MRIRT_ERR_DIMS;                                           // 32-bit element offsets
     if (needVolumes) {
@@ -752,7 +474,8 @@ static int prepare(const MrirtBratsParams* p, const MrirtRenderExt* ext, const v
     int rc = fill_pixel_map(a.map, p->imageSize[0], p->imageSize[1], pitch_px, ext,
                             (variant & 2u) ? 16u : 8u, (variant & 1u) ? 0u : 1u, bandPx);
     if (rc != MRIRT_OK) return rc;
-    fill_grid_dims(a.grid, p->dims, layout);
+    fill_grid_dims(a.grid, p->dims, layout == MRIRT_LAYOUT_VGA ? (uint32_t)MRIRT_LAYOUT_VG : layout);
+    fill_vga_dims(a.vga, p->dims);
     fill_label_addr(a.lab, p->dims, labLayout);
     for (int k = 0; k < 3; ++k) {
         a.bmin[k] = p->volMin[k];
@@ -949,6 +672,7 @@ extern "C" int mrirt_brats_sample_counts(const MrirtBratsParams* p, const MrirtR
 
 template <bool STRICT>
 static int launch_emit(const K1Args& a, const EmitArgs& e, uint32_t layout, hipStream_t s) {
+    if (layout > MRIRT_LAYOUT_QUAD) return MRIRT_ERR_LAYOUT;          // the C5 passes read LINEAR / BRICK / VG / QUAD grids
     const dim3 grid(a.map.chunk * kXcds), block(a.map.blockPx == 8 ? 64 : 256);
     switch (layout) {
         case MRIRT_LAYOUT_LINEAR: hipLaunchKernelGGL((emit_samples_kernel<STRICT, 0>), grid, block, 0, s, a, e); break;
@@ -1018,6 +742,7 @@ static int c5_carve(const MrirtBratsParams* p, uint32_t chunk, void* base, C5Scr
 template <bool STRICT>
 static int c5_launch_plan(const K1Args& a, const EmitArgs& e, uint32_t layout, C5Ray* rays, uint32_t* counter,
                           uint32_t chunk, uint32_t first, hipStream_t s) {
+    if (layout > MRIRT_LAYOUT_QUAD) return MRIRT_ERR_LAYOUT;          // the C5 passes read LINEAR / BRICK / VG / QUAD grids
     const dim3 grid(a.map.chunk * kXcds), block(a.map.blockPx == 8 ? 64 : 256);
     switch (layout) {
         case MRIRT_LAYOUT_LINEAR: hipLaunchKernelGGL((c5_plan_kernel<STRICT, 0>), grid, block, 0, s, a, e, rays, counter, chunk, first); break;
@@ -1031,6 +756,7 @@ static int c5_launch_plan(const K1Args& a, const EmitArgs& e, uint32_t layout, C
 
 template <bool STRICT>
 static int c5_launch_composite(const K1Args& a, uint32_t layout, bool shade, C5Ray* rays, const int16_t* classes, hipStream_t s) {
+    if (layout > MRIRT_LAYOUT_QUAD) return MRIRT_ERR_LAYOUT;          // the C5 passes read LINEAR / BRICK / VG / QUAD grids
     const dim3 grid(a.map.chunk * kXcds), block(a.map.blockPx == 8 ? 64 : 256);
 #define MRIRT_C5C(L, SH) hipLaunchKernelGGL((c5_composite_kernel<STRICT, L, SH>), grid, block, 0, s, a, rays, classes)
     switch (layout) {

@@ -67,6 +67,34 @@ __global__ __launch_bounds__(256) void vec4_build_kernel(const float* __restrict
     dst[e] = o;
 }
 
+// linear fp32 -> VGA: the VG voxel (v and its three lattice differences) written to its slot in each of the three
+// axis-flat copies.  One thread per (padded) voxel of copy `a`, in destination order: a wave writes 8 whole lines.
+__global__ __launch_bounds__(256) void vga_build_kernel(const float* __restrict__ src, float4* __restrict__ dst, FlatAxis f,
+                                                        uint32_t X, uint32_t Y, uint32_t Z, uint32_t nb0, uint32_t nb1, uint64_t total) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;      // float4 index inside this copy
+    if (e >= total) return;
+    const uint32_t in = (uint32_t)(e & 7u);
+    const uint64_t b = e >> 3;
+    const uint32_t bc[3] = { (uint32_t)(b % nb0), (uint32_t)((b / nb0) % nb1), (uint32_t)(b / ((uint64_t)nb0 * nb1)) };
+    uint32_t p[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)                                               // invert o_k(i) = (i >> sh) mul + (i & mask) inner
+        p[k] = (bc[k] << f.sh[k]) + (f.mask[k] ? (in / f.inner[k]) & f.mask[k] : 0u);
+    const uint32_t x = p[0], y = p[1], z = p[2];
+    float4 o = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (x < X && y < Y && z < Z) {
+        const uint64_t sY = X, sZ = (uint64_t)X * Y;
+        auto at = [&](uint32_t xx, uint32_t yy, uint32_t zz) { return src[xx + yy * sY + zz * sZ]; };
+        const uint32_t xp = min(x + 1, X - 1), yp = min(y + 1, Y - 1), zp = min(z + 1, Z - 1);
+        const uint32_t xm = x > 0 ? x - 1 : 0, ym = y > 0 ? y - 1 : 0, zm = z > 0 ? z - 1 : 0;
+        o.x = at(x, y, z);
+        o.y = at(xp, y, z) - at(xm, y, z);
+        o.z = at(x, yp, z) - at(x, ym, z);
+        o.w = at(x, y, zp) - at(x, y, zm);
+    }
+    dst[e] = o;
+}
+
 template <bool HALF>
 __global__ __launch_bounds__(256) void detile_kernel(const void* __restrict__ gathered, void* __restrict__ frame,
                                                      uint32_t width, uint32_t height, int64_t pitch,
@@ -199,9 +227,30 @@ extern "C" int64_t mrirt_vec4_elems(const uint32_t dims[3]) {
     return (int64_t)((dims[0] + 1) / 2) * ((dims[1] + 1) / 2) * ((dims[2] + 1) / 2) * 8;
 }
 
+extern "C" int64_t mrirt_vga_elems(const uint32_t dims[3]) {
+    if (!dims) return 0;
+    return (int64_t)(vga_copy_elems(dims, 0) + vga_copy_elems(dims, 1) + vga_copy_elems(dims, 2));
+}
+
 extern "C" int mrirt_build_vec4_grid(const float* linear, void* vec4_grid, const uint32_t dims[3], uint32_t layout, void* stream) {
     if (!linear || !vec4_grid || !dims) return MRIRT_ERR_NULL;
     for (int k = 0; k < 3; ++k) if (dims[k] < 1) return MRIRT_ERR_DIMS;
+    if (layout == MRIRT_LAYOUT_VGA) {
+        VgaDims v;
+        fill_vga_dims(v, dims);
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        for (int a = 0; a < 3; ++a) {
+            const uint64_t total = vga_copy_elems(dims, a);
+            if (total >= (1ull << 28)) return MRIRT_ERR_DIMS;                      // 32-bit byte offsets inside a copy
+            const FlatAxis& f = v.ax[a];
+            const uint32_t nb0 = f.mul[1] / 8, nb1 = f.mul[2] / f.mul[1];
+            hipLaunchKernelGGL(vga_build_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, s, linear,
+                               reinterpret_cast<float4*>(static_cast<char*>(vec4_grid) + f.baseBytes), f,
+                               dims[0], dims[1], dims[2], nb0, nb1, total);
+            MRIRT_HIP(hipGetLastError());
+        }
+        return MRIRT_OK;
+    }
     if (layout != MRIRT_LAYOUT_VG && layout != MRIRT_LAYOUT_QUAD) return MRIRT_ERR_LAYOUT;
     const uint32_t nbx = (dims[0] + 1) / 2, nby = (dims[1] + 1) / 2;
     const uint64_t total = (uint64_t)mrirt_vec4_elems(dims);

@@ -203,6 +203,35 @@ __device__ __forceinline__ CellOffsets vec4_cell(const GridDims& g, uint32_t ix,
     c.dz = bz ? g.sZ - 4u : 4u;
     return c;
 }
+// VGA ("VG, axis-flat"): the same float4 (v, dx, dy, dz) voxels stored THREE times, in 128-B bricks that are one
+// voxel thick along x, y or z (1x4x2, 4x1x2, 4x2x1).  The samples a wave takes at one march step lie on a sheet
+// parallel to the face its rays entered through (t = t0 + k dt with t0 ON that face), so the copy whose bricks are
+// flat in that direction turns every line a gather touches into eight useful voxels instead of four: fewer distinct
+// lines per wave-level gather, which is what the vector L1's tag pipeline (one look-up per line per clock) charges
+// for.  The wave picks its copy once per packet (entry face of most of its rays); all copies hold the same bits.
+// Separable like the other layouts: element = base + sum over axes of (i >> sh) * mul + (i & mask) * inner.
+struct FlatAxis {
+    uint32_t sh[3], mask[3], inner[3], mul[3];
+    uint32_t wrap[3];          // step to the +1 neighbour from the last slot of a brick: mul - mask * inner
+    uint32_t pad;
+    uint64_t baseBytes;        // byte offset of this copy inside the grid buffer (each copy < 4 GiB)
+};
+struct VgaDims { FlatAxis ax[3]; };
+
+__device__ __forceinline__ CellOffsets flat_cell(const FlatAxis& f, uint32_t ix, uint32_t iy, uint32_t iz) {
+    const uint32_t i[3] = { ix, iy, iz };
+    uint32_t o = 0, d[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const uint32_t lo = i[k] & f.mask[k];
+        o += __umul24(i[k] >> f.sh[k], f.mul[k]) + __umul24(lo, f.inner[k]);      // < 2^24 each factor (dims <= 2^13)
+        d[k] = lo == f.mask[k] ? f.wrap[k] : f.inner[k];
+    }
+    CellOffsets c;
+    c.o = o; c.dx = d[0]; c.dy = d[1]; c.dz = d[2];
+    return c;
+}
+
 template <bool WIDE> __device__ __forceinline__ float4 load_vec4(const void* __restrict__ base, uint32_t elem) {
     const char* b = static_cast<const char*>(base);
     if constexpr (WIDE) return *reinterpret_cast<const float4*>(b + ((uint64_t)elem << 4));

@@ -124,6 +124,36 @@ inline void fill_grid_dims(GridDims& g, const uint32_t dims[3], uint32_t layout)
     }
 }
 
+// VGA: copy `a` has bricks one voxel thick along axis a and 4 x 2 along the other two (in ascending axis order).
+// Returns the float4 elements of copy a (bricks padded to whole lines).
+inline uint64_t vga_copy_elems(const uint32_t dims[3], int a) {
+    uint64_t n = 8;
+    int k4 = 1;                                         // the first non-flat axis gets the 4, the second the 2
+    for (int k = 0; k < 3; ++k) {
+        if (k == a) n *= dims[k];
+        else { n *= k4 ? (dims[k] + 3) / 4 : (dims[k] + 1) / 2; k4 = 0; }
+    }
+    return n;
+}
+inline void fill_vga_dims(VgaDims& v, const uint32_t dims[3]) {
+    uint64_t base = 0;
+    for (int a = 0; a < 3; ++a) {
+        FlatAxis& f = v.ax[a];
+        uint32_t nb[3], innerStride = 1;
+        int k4 = 1;
+        for (int k = 0; k < 3; ++k) {
+            if (k == a) { f.sh[k] = 0; f.mask[k] = 0; f.inner[k] = 0; nb[k] = dims[k]; }
+            else if (k4) { f.sh[k] = 2; f.mask[k] = 3; f.inner[k] = innerStride; innerStride *= 4; nb[k] = (dims[k] + 3) / 4; k4 = 0; }
+            else { f.sh[k] = 1; f.mask[k] = 1; f.inner[k] = innerStride; innerStride *= 2; nb[k] = (dims[k] + 1) / 2; }
+        }
+        f.mul[0] = 8; f.mul[1] = nb[0] * 8; f.mul[2] = nb[0] * nb[1] * 8;       // bricks x-fastest, 8 float4 each
+        for (int k = 0; k < 3; ++k) f.wrap[k] = f.mul[k] - f.mask[k] * f.inner[k];
+        f.pad = 0;
+        f.baseBytes = base << 4;
+        base += vga_copy_elems(dims, a);
+    }
+}
+
 inline void fill_label_addr(LabelAddr& a, const uint32_t dims[3], uint32_t layout) {
     if (layout == MRIRT_LAYOUT_LINEAR) {
         const uint32_t mul[3] = { 1u, dims[0], dims[0] * dims[1] };

@@ -50,7 +50,7 @@ class Grid:
     ``device.create_buffer`` + ``copy_from_numpy`` (inr/viewer/brats_viewer.py:219-230)."""
     data: torch.Tensor            # 1-D, device
     dims: Tuple[int, int, int]    # (X, Y, Z), x fastest in the linear layout
-    layout: str = "linear"        # "linear" | "brick" | "vg" | "quad"
+    layout: str = "linear"        # "linear" | "brick" | "vg" | "quad" | "vga"
     macro: Optional[torch.Tensor] = None   # per 8^3 macro cell: fp32 upper bound (intensities) / any-label word
                                            # (label grids) — what exact empty-space skipping tests (skip=True)
 
@@ -69,10 +69,18 @@ def vec4_elems(dims: Sequence[int]) -> int:
     return int(_lib.lib().mrirt_vec4_elems(d))
 
 
+def vga_elems(dims: Sequence[int]) -> int:
+    """float4 elements of the three axis-flat copies of a "vga" grid together."""
+    d = (C.c_uint32 * 3)(*[int(v) for v in dims])
+    return int(_lib.lib().mrirt_vga_elems(d))
+
+
 def upload_grid(linear: ArrayLike, dims: Sequence[int], layout: str = "brick", stream=None, macro: bool = True) -> Grid:
     """Upload a linear (x-fastest) fp32 / uint32 / uint8 grid and convert it on the device
     (csrc/grid_ops.hip) to ``layout``: "linear" (as is), "brick" (4x4x2 bricks), or for fp32
-    intensities "vg" (float4 value + lattice gradient) / "quad" (float4 xy-neighbours).
+    intensities "vg" (float4 value + lattice gradient) / "quad" (float4 xy-neighbours) / "vga" (the "vg" voxels
+    three times, in bricks one voxel thick along x, y, z: the march reads the copy that is flat along the face its
+    ray packet entered through — 3x the memory, about half the cache lines per gather).
     Load-time, once per volume.  ``macro`` also builds the 8^3 macro-cell summary that
     ``render_brats(..., skip=True)`` needs (a few hundred KB)."""
     dev = _require_gpu()
@@ -89,12 +97,12 @@ def upload_grid(linear: ArrayLike, dims: Sequence[int], layout: str = "brick", s
     macro = _build_macro(t, dims, stream) if macro else None
     if layout == "linear":
         return Grid(t, dims, "linear", macro)
-    if layout in ("vg", "quad"):
+    if layout in ("vg", "quad", "vga"):
         if t.dtype != torch.float32:
             raise TypeError(f"layout {layout!r} is for fp32 intensity grids, got {t.dtype}")
-        out = torch.empty(4 * vec4_elems(dims), dtype=torch.float32, device=dev)
+        out = torch.empty(4 * (vga_elems(dims) if layout == "vga" else vec4_elems(dims)), dtype=torch.float32, device=dev)
         d = (C.c_uint32 * 3)(*dims)
-        code = _lib.LAYOUT_VG if layout == "vg" else _lib.LAYOUT_QUAD
+        code = {"vg": _lib.LAYOUT_VG, "quad": _lib.LAYOUT_QUAD, "vga": _lib.LAYOUT_VGA}[layout]
         _lib.check(_lib.lib().mrirt_build_vec4_grid(_ptr(t), _ptr(out), d, code, _stream_ptr(stream)),
                    "mrirt_build_vec4_grid")
         return Grid(out, dims, layout, macro)
@@ -185,7 +193,7 @@ def _bind_brats(params, intensities, labels, preds, ext, dev, pred_stream: bool 
     if lgrids and "labelLayout" not in e:
         e["labelLayout"] = lgrids[0].layout
     E = render_ext(e)
-    names = {v: k for k, v in (("linear", 0), ("brick", 1), ("vg", 2), ("quad", 3))}
+    names = {v: k for k, v in (("linear", 0), ("brick", 1), ("vg", 2), ("quad", 3), ("vga", 4))}
     lay, lab_lay = names[E.layout], names[E.labelLayout]
     for g, want in [(g, lay) for g in vgrids] + [(g, lab_lay) for g in lgrids]:
         if g.layout != want:
@@ -194,7 +202,8 @@ def _bind_brats(params, intensities, labels, preds, ext, dev, pred_stream: bool 
             raise ValueError(f"grid dims {g.dims} != gParams.dims {tuple(P.dims)}")
     dims = tuple(int(v) for v in P.dims)
     nvox = dims[0] * dims[1] * dims[2]
-    need = {"linear": nvox, "brick": brick_elems(dims), "vg": 4 * vec4_elems(dims), "quad": 4 * vec4_elems(dims)}
+    need = {"linear": nvox, "brick": brick_elems(dims), "vg": 4 * vec4_elems(dims), "quad": 4 * vec4_elems(dims),
+            "vga": 4 * vga_elems(dims)}
     vols = []
     for m in range(4):
         v = intensities[m] if m < len(intensities) else None
