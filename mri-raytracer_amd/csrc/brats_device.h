@@ -45,6 +45,7 @@ struct K1Args {
     uint64_t* stats;
     ExpConsts ec;                 // fp64 constants of the strict exp, SGPR-resident
     uint32_t expSmall;            // intensityAlpha * stepSize <= 1/8: the intensity exp needs no range reduction
+    uint32_t debugFlags;          // experiments only (kernelVariant bits 7..): bit 0 = the slab kernel counts LDS-served samples in stats[1]
 };
 
 template <bool STRICT>
@@ -341,5 +342,8 @@ __device__ __forceinline__ void finish(const K1Args& a, int kind, int64_t oidx, 
         wave_count_add(a.stats + 1, r.nShaded);
     }
 }
+
+// brats_slab.hip: the LDS-staged march (VGA layout, one modality, no overlays), selected by brats_march.hip
+int launch_slab_march(const K1Args& a, bool strict, bool shade, hipStream_t s);
 
 }  // namespace mrirt

@@ -419,7 +419,7 @@ __global__ __launch_bounds__(256) void c5_composite_kernel(const K1Args a, C5Ray
     finish(a, kind, oidx, r);      // the frame so far (complete after the last pass); live-sample counters
 }
 
-struct Prepared { uint32_t layout, math; bool shade, pipe; };
+struct Prepared { uint32_t layout, math; bool shade, pipe, slab; };
 
 // validate + fill the kernel arguments shared by every K1 entry point
 static int prepare(const MrirtBratsParams* p, const MrirtRenderExt* ext, const void* const vol[4],
@@ -522,9 +522,13 @@ static int prepare(const MrirtBratsParams* p, const MrirtRenderExt* ext, const v
     fill_exp_consts(a.ec);
     a.expSmall = (fabsf(p->intensityAlpha * p->stepSize) <= 0.125f) ? 1u : 0u;   // val is in [0, 1]
     a.out = nullptr; a.stats = nullptr;
+    a.debugFlags = (variant >> 7) & 15u;
     cfg.layout = layout; cfg.math = math;
     cfg.shade = ext && ext->shadeMode != 0;
     cfg.pipe = a.nch >= 1 && !(variant & 4u);
+    // the LDS-staged kernel (brats_slab.hip): VGA grids, one modality, no overlays, one packet per workgroup; variant bit 6
+    cfg.slab = layout == MRIRT_LAYOUT_VGA && (variant & 64u) != 0 && cfg.pipe && a.nch == 1 && p->showSeg == 0 && p->showPred == 0 &&
+               a.map.blockPx == 8;
     return MRIRT_OK;
 }
 
@@ -585,6 +589,7 @@ extern "C" int mrirt_render_brats_ex(const MrirtBratsParams* p, const MrirtRende
     a.stats = stats_dev;
     if (a.map.numBlocks == 0) return MRIRT_OK;   // a rank that owns no tile
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (cfg.slab) return launch_slab_march(a, cfg.math == MRIRT_MATH_STRICT, cfg.shade, s);
     return cfg.math == MRIRT_MATH_STRICT ? launch_layout<true>(a, cfg.layout, cfg.shade, cfg.pipe, s)
                                          : launch_layout<false>(a, cfg.layout, cfg.shade, cfg.pipe, s);
 }

@@ -10,12 +10,12 @@ OUT=$REPO/build_exp
 mkdir -p $OUT/obj
 FLAGS="-O3 --offload-arch=gfx950 -ffp-contract=off -fPIC -std=c++17 -Wall -I$REPO/include"
 OBJS=""
-for f in brats_march volume_march grid_ops inr_mlp; do
+for f in brats_march brats_slab volume_march grid_ops inr_mlp; do
   if [ "$f.hip" == "$SRC" ]; then
     /opt/rocm/bin/hipcc $FLAGS "$@" -c $CS/$f.hip -o $OUT/obj/${f}_$NAME.o
     OBJS="$OBJS $OUT/obj/${f}_$NAME.o"
   else
-    if [ ! -f $OUT/obj/$f.o ] || [ $CS/$f.hip -nt $OUT/obj/$f.o ] || [ $CS/mrirt_device.h -nt $OUT/obj/$f.o ] || [ $CS/mrirt_host.h -nt $OUT/obj/$f.o ]; then
+    if [ ! -f $OUT/obj/$f.o ] || [ $CS/$f.hip -nt $OUT/obj/$f.o ] || [ $CS/mrirt_device.h -nt $OUT/obj/$f.o ] || [ $CS/mrirt_host.h -nt $OUT/obj/$f.o ] || [ $CS/brats_device.h -nt $OUT/obj/$f.o ]; then
       /opt/rocm/bin/hipcc $FLAGS -c $CS/$f.hip -o $OUT/obj/$f.o
     fi
     OBJS="$OBJS $OUT/obj/$f.o"

@@ -16,7 +16,8 @@ for (phi, theta, up, radius) in ((80, 25, None, 3.0), (10, 0, None, 3.0), (90, 9
             a, sa = mrirt.render_brats(p, [gv], ext=dict(ext, layout="vg"), stats=True)
             b, sb = mrirt.render_brats(p, [ga], ext=dict(ext, layout="vga"), stats=True)
             c = mrirt.render_brats(p, [ga], ext=dict(ext, layout="vga", kernelVariant=4))      # generic kernel
-            same = torch.equal(a, b) and sa == sb and torch.equal(a, c)
+            d, sd = mrirt.render_brats(p, [ga], ext=dict(ext, layout="vga", kernelVariant=64), stats=True)   # LDS-staged kernel
+            same = torch.equal(a, b) and sa == sb and torch.equal(a, c) and torch.equal(a, d) and sa == sd
             ok &= same
-            print(phi, theta, up, radius, shade, math_, "same" if same else f"DIFF {float((a-b).abs().max())} {float((a-c).abs().max())}", sa["live_samples"])
+            print(phi, theta, up, radius, shade, math_, "same" if same else f"DIFF {float((a-b).abs().max())} {float((a-c).abs().max())} slab {float((a-d).abs().max())} {sd}", sa["live_samples"])
 print("ALL OK" if ok else "FAILED")
