@@ -59,7 +59,7 @@ def parse():
     ap.add_argument("--march-steps", type=int, default=512)
     ap.add_argument("--math", default="strict", choices=["strict", "fast"])
     ap.add_argument("--layout", default="auto", choices=["auto", "vg", "vga", "quad", "brick", "linear"],
-                    help="HBM layout of the volume; auto = vg (value+gradient float4 bricks) when shading, quad otherwise")
+                    help="HBM layout of the volume; auto = vga (value+gradient float4 voxels in three axis-flat brick copies) when shading, quad otherwise")
     ap.add_argument("--no-shade", action="store_true", help="reference-only K1 (no gradient shading)")
     ap.add_argument("--alpha", type=float, default=16.0, help="intensityAlpha (16 = dense preset: ERT fires)")
     ap.add_argument("--variant", type=int, default=0, help="kernelVariant (experiments)")
@@ -237,7 +237,7 @@ def main():
     vol = synth.synth_volume(n)                                   # host, deterministic
     params = synth.brats_scene(n, image, a.march_steps, channels=1, intensity_alpha=a.alpha)
     if a.layout == "auto":
-        a.layout = "quad" if a.no_shade else "vg"
+        a.layout = "quad" if a.no_shade else "vga"
     ext = {} if a.no_shade else dict(synth.SHADE_EXT)
     ext.update(math=a.math, layout=a.layout, kernelVariant=a.variant)
     grid = mrirt.upload_grid(vol, (n, n, n), a.layout)            # resident in HBM (bricked on device)

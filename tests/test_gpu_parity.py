@@ -292,7 +292,13 @@ def test_full_size_properties(env):
     gq = mrirt.upload_grid(vol, (n, n, n), "quad")
     u0 = mrirt.render_brats(p, [gl])
     assert torch.equal(u0, mrirt.render_brats(p, [gq])) and torch.equal(u0, mrirt.render_brats(p, [gv]))
-    del gq, gv, u0, c
+    # the three axis-flat copies (VGA): register-gather kernels and the LDS-staged slab kernel (kernelVariant 64)
+    ga = mrirt.upload_grid(vol, (n, n, n), "vga")
+    for variant in (0, 64):
+        d, sd = mrirt.render_brats(p, [ga], ext=dict(ext, kernelVariant=variant), stats=True)
+        assert torch.equal(a, d) and sd == sa, f"VGA grid, kernel variant {variant}: must not change a single bit"
+        assert torch.equal(u0, mrirt.render_brats(p, [ga], ext=dict(kernelVariant=variant)))
+    del gq, gv, ga, u0, c, d
     img = b.cpu().numpy()
     assert np.isfinite(img).all() and img[..., :3].min() >= 0.0 and np.all(img[..., 3] == 1.0)
     assert np.array_equal(img[..., 0], img[..., 1]) and np.array_equal(img[..., 0], img[..., 2])   # grey emission

@@ -159,3 +159,43 @@ def test_k2_random_cameras_and_slabs(env, seed):
     assert st["live_samples"] == aux["live_samples"]
     c8 = mrirt.render.build_cell8(u8.reshape(-1), dims, "u8")
     assert np.array_equal(mrirt.render_volume_u8(p, c8, mode="cell8", ext=ext).cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_vga_layout_and_slab_kernel_random_cameras(env, seed):
+    """VGA (three axis-flat copies) through the register-gather kernels and through the LDS-staged slab kernel, against
+    the C oracle: cameras around and inside the volume so that every copy (x-, y-, z-flat) and both march
+    directions are read, windows that touch the volume's border, grids barely larger than a plane window,
+    packets whose rays enter through different faces (those lanes take the global fall-back)."""
+    mrirt, synth, oc = env
+    rng = np.random.default_rng(7000 + seed)
+    dims = tuple(int(v) for v in rng.integers(20, 56, 3))
+    vol = synth.synth_volume(0, 50 + seed, phase=float(rng.uniform(0, 3)), dims=dims)
+    ups = (None, (1.0, 0.0, 0.0), (0.0, 0.0, 1.0))
+    cam = synth.bench_camera(radius=float(rng.choice([0.2, 0.8, 2.0, 3.5])), phi_deg=float(rng.uniform(3, 177)),
+                             theta_deg=float(rng.uniform(0, 360)), world_up=None if seed % 3 == 0 else np.array(ups[seed % 3], np.float32))
+    shade = bool(seed & 1)
+    p = synth.brats_scene(0, 0, int(rng.integers(40, 260)), dims=dims, image_hw=(int(rng.integers(9, 90)), int(rng.integers(9, 90))),
+                          channels=1, intensity_alpha=float(rng.choice([0.4, 16.0, 60.0])), camera=cam, fov_deg=float(rng.uniform(20, 95)))
+    p["voxelSize"] = (p["voxelSize"] * rng.uniform(0.6, 1.7, 3)).astype(np.float32)
+    p["gamma"] = float(rng.choice([1.0, 1.0, 1.8]))
+    ext = dict(synth.SHADE_EXT) if shade else {}
+    okeys = ("shadeMode", "ka", "kd", "ks", "specPow2", "gradEps")
+    ref, aux = oc.brats_main(p, [vol], None, None, {k: v for k, v in ext.items() if k in okeys}, return_aux=True)
+    g = mrirt.upload_grid(vol, dims, "vga")
+    for variant in (0, 4, 64):                     # pipelined gathers, generic kernel, LDS-staged slab kernel
+        got, st = mrirt.render_brats(p, [g], ext=dict(ext, math="strict", kernelVariant=variant), stats=True)
+        assert np.array_equal(got.cpu().numpy(), ref), (seed, variant, dims, float(np.abs(got.cpu().numpy() - ref).max()))
+        assert st["live_samples"] == aux["live_samples"] and st["shaded_samples"] == aux["shaded_samples"]
+
+
+def test_slab_kernel_refuses_grids_smaller_than_a_window(env):
+    mrirt, synth, oc = env
+    dims = (12, 30, 30)
+    vol = synth.synth_volume(0, 3, dims=dims)
+    p = synth.brats_scene(0, 0, 64, dims=dims, image_hw=(16, 16), channels=1)
+    g = mrirt.upload_grid(vol, dims, "vga")
+    with pytest.raises(mrirt._lib.MrirtError):
+        mrirt.render_brats(p, [g], ext=dict(kernelVariant=64))
+    ref = oc.brats_main(p, [vol], None, None)
+    assert np.array_equal(mrirt.render_brats(p, [g]).cpu().numpy(), ref)
