@@ -332,7 +332,8 @@ def main():
         my_live, my_shaded = st["live_samples"], st["shaded_samples"]
         px = local.numel() // 4
         alg_bytes = my_live * BYTES_PER_SAMPLE + my_shaded * BYTES_PER_SHADED + px * BYTES_PER_PIXEL
-        compulsory = grid.nbytes + px * BYTES_PER_PIXEL            # the volume once + this rank's framebuffer
+        # the volume once + this rank's framebuffer (vga holds three copies of the voxels; a frame reads essentially one)
+        compulsory = grid.nbytes // (3 if a.layout == "vga" else 1) + px * BYTES_PER_PIXEL
         profiled = world == 1 and a.variant == 0 and a.alpha == 16.0 and not a.force_exchange
         key = (f"{'C3' if not a.no_shade else 'K1'}:{n}:{image}:{a.march_steps}:{a.layout}:{a.math}:"
                f"{'shade' if not a.no_shade else 'plain'}")
