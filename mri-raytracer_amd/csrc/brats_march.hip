@@ -190,6 +190,95 @@ __global__ __launch_bounds__(256, (LABELS || SKIP) ? 3 : 4) void brats_march_pip
     finish(a, kind, oidx, r);
 }
 
+// ---------------------------------------------------------------------------------------
+// Rolling pipeline for the float4 voxel layouts (VG / VGA) with 2..4 modalities — the viewer's shaded
+// four-modality frame.  A stage of the kernel above holds every modality's gathers of a step (8 float4 = 32 registers
+// per modality, two stages), which only fits for one modality; here the unit in flight is one (step, modality) PAIR:
+// while pair k is blended and accumulated, pair k+1's eight gathers are out — the next modality of the same cell, or
+// modality 0 of the next step's cell (speculative, clamped addresses).  Two tap sets whatever NCH; the label
+// fetches travel with modality 0.  Same arithmetic in the same order as the shader's modality loop.
+// ---------------------------------------------------------------------------------------
+template <bool STRICT, int LAYOUT, bool SHADE, int NCH, bool GAMMA1, bool LABELS>
+__global__ __launch_bounds__(256, 2) void brats_march_roll_kernel(const K1Args a) {
+    using Mm = M<STRICT>;
+    uint32_t px, py;
+    int64_t oidx;
+    const int kind = map_pixel(a.map, px, py, oidx);
+    RayState r = { a.bg[0], a.bg[1], a.bg[2], 1.0f, 0u, 0u };
+    float ro[3] = { 0.0f, 0.0f, 0.0f }, rd[3] = { 0.0f, 0.0f, 1.0f }, t0 = 0.0f, t1 = 0.0f;
+    const bool marches = kind == 1 && setup_ray(a, px, py, ro, rd, t0, t1) && t0 < t1 && 1.0f > a.ert;
+    WaveGrid<LAYOUT> wg;
+    if constexpr (LAYOUT == 4) wg.f = a.vga.ax[vga_pick_axis(a, ro, rd, marches)];
+    else wg.g = &a.grid;
+    if (marches) {
+        float t = t0;
+        Taps<LAYOUT, SHADE> tp[2];                                  // pair k lives in tp[k & 1]
+        Cell cs[2];                                                 // cell of the step a pair belongs to: step parity
+        Labels lb[2];
+        int64_t row = 0;
+        if constexpr (LABELS) { if (a.classStream != nullptr) row = a.rayOffsets[(int64_t)py * a.map.width + px]; }
+        locate<STRICT>(a, ro, rd, t, cs[0]);
+        tp[0].template issue<false>(wg.base(a.vol[a.chan[0]]), wg.dims(), cs[0]);
+        if constexpr (LABELS) fetch_labels(a, cs[0], lb[0], row++);
+        bool done = false;
+        while (!done) {
+            // two steps per trip: 2 NCH pairs, so the buffer parity of a pair is a compile-time value
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) {
+                if (done) break;
+                float v = 0.0f, g[3] = { 0.0f, 0.0f, 0.0f };
+                const float tn = t + a.stepSize;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    const int k = sp * NCH + c;                     // pair index inside the trip
+                    // request pair k + 1
+                    if (c + 1 < NCH) {
+                        tp[(k + 1) & 1].template issue<false>(wg.base(a.vol[a.chan[c + 1]]), wg.dims(), cs[sp]);
+                    } else {
+                        locate<STRICT>(a, ro, rd, tn, cs[sp ^ 1]);  // the next step's cell (the ray may end here: harmless)
+                        tp[(k + 1) & 1].template issue<false>(wg.base(a.vol[a.chan[0]]), wg.dims(), cs[sp ^ 1]);
+                        if constexpr (LABELS) {
+                            if (a.classStream != nullptr && !(tn < t1)) { lb[sp ^ 1].seg = a.showSeg != 0 ? sample_label(a.labels, a.lab, cs[sp ^ 1].q, a.hiLab) : 0u; lb[sp ^ 1].pred = 0u; }
+                            else fetch_labels(a, cs[sp ^ 1], lb[sp ^ 1], row++);
+                        }
+                    }
+                    // consume pair k: brats_rt.slang:123-130, ascending modality order
+                    float sv, gm[3];
+                    tp[k & 1].template eval<STRICT>(cs[sp], sv, gm);
+                    const float w = a.weight[a.chan[c]];
+                    v = Mm::mad(sv, w, v);
+                    if constexpr (SHADE) {
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) g[q] = Mm::mad(gm[q], w, g[q]);
+                    }
+                    // one pair ahead, no more: left alone the scheduler hoists every pair's gathers of the trip to its top
+                    // (8 x 32 registers) and spills
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (LABELS) composite<STRICT, SHADE, GAMMA1>(a, rd, lb[sp], v, g, r);
+                else { const Labels none = { 0u, 0u }; composite<STRICT, SHADE, GAMMA1, false>(a, rd, none, v, g, r); }
+                t = tn;
+                done = !(t < t1 && r.T > a.ert);
+            }
+        }
+    }
+    finish(a, kind, oidx, r);
+}
+
+template <bool STRICT, int LAYOUT, bool SHADE, int NCH>
+static int launch_roll(const K1Args& a, hipStream_t s) {
+    const dim3 grid(a.map.chunk * kXcds), block(a.map.blockPx == 8 ? 64 : 256);
+    const bool overlays = a.showSeg != 0 || a.showPred != 0;
+    if (STRICT && a.gamma == 1.0f) {
+        if (overlays) hipLaunchKernelGGL((brats_march_roll_kernel<STRICT, LAYOUT, SHADE, NCH, STRICT, true>), grid, block, 0, s, a);
+        else          hipLaunchKernelGGL((brats_march_roll_kernel<STRICT, LAYOUT, SHADE, NCH, STRICT, false>), grid, block, 0, s, a);
+    } else {
+        hipLaunchKernelGGL((brats_march_roll_kernel<STRICT, LAYOUT, SHADE, NCH, false, true>), grid, block, 0, s, a);
+    }
+    MRIRT_HIP(hipGetLastError());
+    return MRIRT_OK;
+}
+
 template <bool STRICT, int LAYOUT, bool SHADE, int NCH>
 static int launch_pipe(const K1Args& a, hipStream_t s) {
     const dim3 grid(a.map.chunk * kXcds), block(a.map.blockPx == 8 ? 64 : 256);
@@ -215,11 +304,27 @@ static int launch_pipe(const K1Args& a, hipStream_t s) {
 
 template <bool STRICT, int LAYOUT, bool SHADE>
 static int launch(const K1Args& a, bool pipe, hipStream_t s) {
-    if constexpr (LAYOUT == 2) {                      // VG: 8 float4 per modality per stage -> one modality
+    if constexpr (LAYOUT == 2) {                      // VG: 8 float4 per modality per stage -> one modality; more: rolling pairs
         if (pipe && a.nch == 1 && !a.grid.wide) return launch_pipe<STRICT, 2, SHADE, 1>(a, s);
+        if (pipe && !a.grid.wide && a.skipMask == nullptr && a.showSeg == 0 && a.showPred == 0) {   // (with overlays the generic kernel measured faster)
+            switch (a.nch) {
+                case 2: return launch_roll<STRICT, 2, SHADE, 2>(a, s);
+                case 3: return launch_roll<STRICT, 2, SHADE, 3>(a, s);
+                case 4: return launch_roll<STRICT, 2, SHADE, 4>(a, s);
+                default: break;
+            }
+        }
     }
     if constexpr (LAYOUT == 4) {                      // VGA: as VG; every copy is < 4 GiB by construction (prepare())
         if (pipe && a.nch == 1) return launch_pipe<STRICT, 4, SHADE, 1>(a, s);
+        if (pipe && a.skipMask == nullptr && a.showSeg == 0 && a.showPred == 0) {
+            switch (a.nch) {
+                case 2: return launch_roll<STRICT, 4, SHADE, 2>(a, s);
+                case 3: return launch_roll<STRICT, 4, SHADE, 3>(a, s);
+                case 4: return launch_roll<STRICT, 4, SHADE, 4>(a, s);
+                default: break;
+            }
+        }
     }
     if constexpr (LAYOUT == 3) {                      // QUAD: 2 float4 per modality per stage -> up to four
         if (pipe && !a.grid.wide) {

@@ -1,13 +1,20 @@
 """INR forward (bf16 MFMA) against the goldens captured from the reference's inr/inr/model.py and
-against the fp32 oracle.  Tolerances: the kernel multiplies in bf16 (split-bf16
-first layer, fp32 accumulate), so logits are held to a relative bound scaled by the logit range
-and the classifier to argmax agreement; every disagreement must be a near-tie in the fp32 logits."""
+against the fp32 oracle.  Tolerances: the kernel multiplies in bf16 (split-bf16 first layer, fp32
+accumulate), so logits are held to a relative bound scaled by the logit range and the classifier to argmax
+agreement; every disagreement must be a near-tie in the fp32 logits.
+
+Measured (profiles/r02_inr_accuracy.txt, tools/inr_accuracy.py): max |dlogit| = 4e-3 .. 7.8e-3 of the logit range on
+every network tried; argmax agreement 1.0 on the reference-generated goldens and 0.9952 .. 0.9975 on 300 k random points
+of randomly initialised networks, whose 4-class heads are full of near-ties (the largest fp32 top-2 gap among all
+disagreements is 6.7e-3 of the range).  SURVEY.md 8c's 99.9 % is therefore not reachable with 8-bit mantissas in
+the hidden layers on such heads; the tests below hold the kernel to what it achieves with a small margin (logits
+1e-2 of range, agreement >= 0.995, every disagreement a tie within 1e-2 of range)."""
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 
-LOGIT_REL_TOL = 2e-2        # of max|logit|: bf16 hidden layers (8-bit mantissa), 4 layers deep
+LOGIT_REL_TOL = 1e-2        # of max|logit|: bf16 hidden layers (8-bit mantissa), 4 layers deep; measured <= 7.8e-3
 ARGMAX_AGREE = 0.995
 
 
@@ -64,7 +71,7 @@ def test_predict_volume_matches_reference_goldens(env, tag, nl):
         for i, j, k in bad:
             top = np.sort(logits[i, j, k])[-2:]
             assert top[1] - top[0] <= LOGIT_REL_TOL * np.abs(logits).max()
-    assert (pred == want).mean() >= 0.97
+    assert (pred == want).mean() >= 0.99                    # 120 voxels: at most one near-tie may flip (measured: none)
 
 
 def test_predict_volume_large_agreement(env):
@@ -91,7 +98,7 @@ def test_siren_matches_fp64_fixture(env, tag, depth):
     want = s[f"{tag}_logits"]
     got = mrirt.inr.siren_apply(params, s[f"{tag}_x"]).cpu().numpy()
     assert got.shape == want.shape
-    assert np.abs(got - want).max() <= 3e-2 * max(1.0, np.abs(want).max())
+    assert np.abs(got - want).max() <= 1e-2 * max(1.0, np.abs(want).max())          # measured 4e-3 / 5e-3
 
 
 def test_inr_argument_errors(env):
@@ -164,6 +171,6 @@ def test_siren_with_device_built_inputs_matches_fp64(env):
     got, _ = inr._forward(net, torch.from_numpy(coords).cuda(), torch.from_numpy(feats).cuda(), n, True, False)
     got = got.cpu().numpy()
     scale = max(1.0, np.abs(want).max())
-    assert np.abs(got - want).max() <= 3e-2 * scale, np.abs(got - want).max() / scale
+    assert np.abs(got - want).max() <= 1e-2 * scale, np.abs(got - want).max() / scale       # measured 5.6e-3
     raw = inr.siren_apply({f"l{i}": {"w": p["W"], "b": p["b"]} for i, p in enumerate(params)}, x.astype(np.float32), w0=w0).cpu().numpy()
     assert np.abs(got - raw).max() <= 1e-2 * scale

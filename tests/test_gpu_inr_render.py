@@ -74,15 +74,18 @@ def test_c5_layers(setup, layout):
     logits = onp.apply_mlp(s["mlp"], x)
     want = np.argmax(logits, axis=-1)
     agree = (classes == want)
-    assert agree.mean() >= 0.99, agree.mean()
+    assert agree.mean() >= 0.995, agree.mean()                       # measured 0.996-0.998 (profiles/r02_inr_accuracy.txt)
     top2 = np.sort(logits[~agree], axis=-1)[:, -2:]
-    assert np.all(top2[:, 1] - top2[:, 0] <= 2e-2 * np.abs(logits).max()), "every disagreement is a near-tie"
+    assert np.all(top2[:, 1] - top2[:, 0] <= 1e-2 * np.abs(logits).max()), "every disagreement is a near-tie"
     ref = onp.brats_main_inr(p, s["vols"], s["mlp"], s["K"], s["zmu"], s["zsg"], labels=s["lab"])
     d = np.abs(img - ref)[..., :3].max(axis=-1)
     # a ray is exact unless one of its ~40 samples sits on a logit near-tie (<1 % of samples do)
     flipped_rays = sum(1 for o, c in zip(offsets, counts.reshape(-1)) if c and not agree[o:o + c].all()) / counts.size
     assert (d > 1e-4).mean() <= flipped_rays + 1e-9, "only rays holding a flipped class may differ"
-    assert (d <= 1e-4).mean() >= 0.90 and d.mean() < 2e-3
+    # ... which IS the floor on exact pixels: 1 - P(a ray holds a near-tie sample).  With ~0.3 % of the samples flipping and
+    # ~25-40 composited samples per marching ray that is ~0.9-0.97 (0.967 measured in round 1); a fixed floor would only
+    # restate the measured flip rate, so the bound on it is the sample-level agreement above.
+    assert flipped_rays <= 0.15 and d.mean() < 2e-3
     assert d.max() <= 0.25          # one flipped overlay step: alpha*T*|lut.rgb| with alpha = 1 - e^{-0.9*dt*1.5}
 
 
@@ -222,8 +225,8 @@ def test_c5_as_named_siren_4x256_512x512_256_samples():
     agree = have == want
     top2 = np.sort(rec["l"][seen][~agree], axis=-1)[:, -2:]
     scale = np.abs(rec["l"][seen]).max()
-    assert agree.mean() >= 0.97, agree.mean()
-    assert np.all(top2[:, 1] - top2[:, 0] <= 3e-2 * scale), "every disagreement is a near-tie"
+    assert agree.mean() >= 0.995, agree.mean()                       # measured 0.9967
+    assert np.all(top2[:, 1] - top2[:, 0] <= 1e-2 * scale), "every disagreement is a near-tie"   # measured 6.5e-3
     print(f"C5 SIREN band: {seen.sum()} samples, argmax agreement {agree.mean():.5f}, worst tie gap "
           f"{(top2[:, 1] - top2[:, 0]).max() / scale if len(top2) else 0:.2e} of range; "
           f"frame: {a['queries']} queries chunked vs {a0['queries']} whole-ray, {a['live_samples']} live")
