@@ -598,6 +598,12 @@ __global__ __launch_bounds__(512) void inr_forward_kernel(const InrArgs a) {
 // its own 64 output features of the last hidden layer (still in registers) with its slice of the head and
 // leaves 4 partial logits per point in LDS; wave g sums the four partials of group g in a fixed order.  No weight
 // traffic at all after the prologue, one workgroup barrier per layer phase (128 MFMAs per wave apart).
+// Tried and measured no faster (round 2, s_memtime stamps + wall): a second schedule that chains the passes across phase
+// and round boundaries with two write-only barriers per phase (post-op always under the next pass, ring running on
+// into the next layer) — 20.0 k cycles per round against 18.1 k here; a micro-benchmark of the pass (tools/micro/
+// mfma_pace.hip) shows why neither wins: 16 MFMAs + 16 LDS reads take 549 cycles, and the 16 v_sin + 8 converts of the
+// previous tile's activation add ~160 on top instead of hiding (709) — with one wave per SIMD the VALU work of the gaps
+// that carry two sines overflows the 24 issue cycles an MFMA leaves.
 // Same packed image, same arithmetic per point (accumulator starts at the bias, k steps in ascending order):
 // bit-identical logits to the streaming kernel for the hidden layers' inputs; the head sums four k-quarter
 // partials in fp32 instead of one running chain, so logits may differ from it in the last bit (the tests hold both
@@ -636,7 +642,7 @@ __device__ __forceinline__ void mfma_drain(f32x16& acc) { asm volatile("s_nop 15
 template <bool SIREN>
 __global__ __launch_bounds__(256, 1) void inr_ws_kernel(const InrArgs a) {
 #ifndef MRIRT_WS_RD
-#define MRIRT_WS_RD 6
+#define MRIRT_WS_RD 4
 #endif
     constexpr int G = kWsGroups, NH = 3, KS = 16, RD = MRIRT_WS_RD;      // RD: B fragments in flight ahead of their MFMA
     constexpr int kActQ = G * 2 * KS * 64;               // uint4: [group][parity][k step][lane]   128 KiB

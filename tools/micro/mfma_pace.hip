@@ -83,6 +83,76 @@ __global__ __launch_bounds__(256, 1) void k(const uint4* __restrict__ w, unsigne
     sink[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// The weight-stationary kernel's pass structure: 16 MFMAs into acc while the PREVIOUS pass's accumulator is activated
+// (2 v_sin per step in steps 2..9, packed converts), one B fragment per step from LDS.  VARIANT 0: accumulators in
+// VGPRs (VALU reads them directly); 1: no activation at all; 2: activation on registers MFMAs never wrote;
+// 3: accumulators in AGPRs, read out with v_accvgpr_read.
+template <int VARIANT>
+__global__ __launch_bounds__(256, 1) void kpass(const uint4* __restrict__ w, unsigned long long* out, float* sink) {
+    __shared__ u32x4 lds[16 * 64];
+    const int lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < 16 * 64; i += 256) lds[i] = (u32x4){ (unsigned)i, 1u, 2u, 3u };
+    __syncthreads();
+    bf16x8 A[16], Br[4];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) A[i] = __builtin_bit_cast(bf16x8, w[i * 64 + lane]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) Br[i] = __builtin_bit_cast(bf16x8, w[(16 + i) * 64 + lane]);
+    f32x16 acc[2] = { (f32x16)(0.0f), (f32x16)(0.0f) }, other = (f32x16)(0.25f);
+    typedef __attribute__((address_space(3))) u32x4 lq;
+    lq* base = (lq*)lds + lane;
+    float keep = 0.0f;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 bq = (f32x4)(0.0f);
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < 32; ++it) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {                     // two passes per trip: acc[p] accumulates, acc[p ^ 1] is activated
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                if (VARIANT == 3) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[p]) : "a"(A[ks]), "v"(Br[ks % 4]));
+                else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[p]) : "a"(A[ks]), "v"(Br[ks % 4]));
+                Br[ks % 4] = __builtin_bit_cast(bf16x8, base[ks * 64]);
+                if (VARIANT == 4) {                       // one value per step over all 16 steps: bias add + sin, convert every second step
+                    f32x16& src = acc[p ^ 1];
+                    if (ks == 0) asm volatile("s_nop 15" : "+v"(src));
+                    if ((ks & 3) == 0) bq = __builtin_bit_cast(f32x4, base[(ks >> 2) * 64 + 8]);
+                    const float bb = (ks & 3) == 0 ? bq.x : ((ks & 3) == 1 ? bq.y : ((ks & 3) == 2 ? bq.z : bq.w));
+                    src[ks] = __builtin_amdgcn_sinf(src[ks] + bb);
+                    if (ks & 1) {
+                        typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+                        bf2 pk = { (__bf16)src[ks - 1], (__bf16)src[ks] };
+                        keep += __builtin_bit_cast(float, pk);
+                    }
+                }
+                if (VARIANT != 1 && VARIANT != 4 && ks >= 2 && ks <= 9) {
+                    f32x16& src = VARIANT == 2 ? other : acc[p ^ 1];
+                    if (ks == 2) asm volatile("s_nop 15" : "+v"(src));
+                    const float a0 = __builtin_amdgcn_sinf(src[2 * ks - 4]), a1 = __builtin_amdgcn_sinf(src[2 * ks - 3]);
+                    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+                    bf2 pk = { (__bf16)a0, (__bf16)a1 };
+                    keep += __builtin_bit_cast(float, pk);
+                    src[2 * ks - 4] = a0 * 0.5f;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (lane == 0) out[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+    float s = keep;
+    for (int i = 0; i < 16; ++i) s += acc[0][i] + acc[1][i] + other[i];
+    sink[blockIdx.x * 256 + threadIdx.x] = s;
+}
+template <int VARIANT> void runpass(const char* name, uint4* w, unsigned long long* out, float* sink) {
+    for (int r = 0; r < 3; ++r) hipLaunchKernelGGL(kpass<VARIANT>, dim3(256), dim3(256), 0, 0, w, out, sink);
+    hipDeviceSynchronize();
+    std::vector<unsigned long long> h(1024);
+    hipMemcpy(h.data(), out, 1024 * 8, hipMemcpyDeviceToHost);
+    std::sort(h.begin(), h.end());
+    printf("%-46s median %.1f cycles per 16-MFMA pass (ideal 512)\n", name, h[512] / 64.0);
+}
+
 template <int MODE> void run(const char* name, uint4* w, unsigned long long* out, float* sink) {
     for (int r = 0; r < 3; ++r) hipLaunchKernelGGL(k<MODE>, dim3(256), dim3(256), 0, 0, w, out, sink);
     hipDeviceSynchronize();
@@ -110,6 +180,11 @@ int main() {
     run<12>("asm + ds_read every 2nd MFMA", w, out, sink);
     run<13>("asm + 2 x ds_read_b64 per step", w, out, sink);
     run<5>("builtin", w, out, sink);
+    runpass<1>("pass: no activation", w, out, sink);
+    runpass<0>("pass: activation of the other VGPR accumulator", w, out, sink);
+    runpass<2>("pass: activation of registers MFMA never wrote", w, out, sink);
+    runpass<3>("pass: accumulators in AGPRs (accvgpr_read)", w, out, sink);
+    runpass<4>("pass: 1 value/step x 16, bias add + sin + cvt", w, out, sink);
     run<6>("builtin + ds_read_b128 per step", w, out, sink);
     return 0;
 }
