@@ -647,14 +647,14 @@ __global__ __launch_bounds__(256, 1) void inr_ws_kernel(const InrArgs a) {
     constexpr int G = kWsGroups, NH = 3, KS = 16, RD = MRIRT_WS_RD;      // RD: B fragments in flight ahead of their MFMA
     constexpr int kActQ = G * 2 * KS * 64;               // uint4: [group][parity][k step][lane]   128 KiB
     constexpr int kInQ = G * 2 * 64;                     // layer-0 B fragments (k steps 0, 1)       8 KiB
-    constexpr int kPartQ = G * 4 * 32;                   // head partials [group][wave][point]       8 KiB
+    constexpr int kPartQ = 0;                            // (head partials of an earlier k-split head: gone)
     constexpr int kBiasQ = (4 * 256 + 32) / 4;           // padded biases                          4.1 KiB
     constexpr int kW0Q = 16 * 64, kWoQ = 16 * 64;        // layer-0 and head A fragments (all waves')   16 + 16 KiB
-    constexpr int kW0Off = kActQ + kInQ + kPartQ + kBiasQ, kWoOff = kW0Off + kW0Q;
-    __shared__ uint4 ldsAll[kActQ + kInQ + kPartQ + kBiasQ + kW0Q + kWoQ];
+    constexpr int kW3Q = 4 * 4 * 64;                     // four layer-3 A fragments per wave that do not fit the registers  16 KiB
+    constexpr int kW0Off = kActQ + kInQ + kPartQ + kBiasQ, kWoOff = kW0Off + kW0Q, kW3Off = kWoOff + kWoQ;
+    __shared__ uint4 ldsAll[kActQ + kInQ + kPartQ + kBiasQ + kW0Q + kWoQ + kW3Q];
     uint4* const ldsAct = ldsAll;
     uint4* const ldsIn = ldsAll + kActQ;
-    float4* const ldsPart = reinterpret_cast<float4*>(ldsAll + kActQ + kInQ);
     const float4* const ldsBias = reinterpret_cast<const float4*>(ldsAll + kActQ + kInQ + kPartQ);
 
     int64_t nPts = a.n;
@@ -682,8 +682,12 @@ __global__ __launch_bounds__(256, 1) void inr_ws_kernel(const InrArgs a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-                Wh[l][j][ks] = __builtin_bit_cast(bf16x8, wp[(size_t)(a.L.fragOff[l + 1] + (2 * w + j) * KS + ks) * 64 + lane]);
+            for (int ks = 0; ks < KS; ++ks) {
+                const uint4 fr = wp[(size_t)(a.L.fragOff[l + 1] + (2 * w + j) * KS + ks) * 64 + lane];
+                // 96 fragments = 384 registers is what fits beside the accumulators: the last four of layer 3 go through LDS
+                if (l == NH - 1 && j == 1 && ks >= KS - 4) ldsAll[kW3Off + (w * 4 + (ks - (KS - 4))) * 64 + lane] = fr;
+                else Wh[l][j][ks] = __builtin_bit_cast(bf16x8, fr);
+            }
     // layer 0 (2 k steps per out tile) and the head (k-quarter per wave) are 4 + 4 fragments per wave: they stay in
     // LDS (lane-linear, read just before use) — 400 + of the 512 registers as weights left the allocator no room
     for (uint32_t f = w; f < 16; f += 4) {
@@ -701,7 +705,8 @@ __global__ __launch_bounds__(256, 1) void inr_ws_kernel(const InrArgs a) {
     lds_q* bIn = (lds_q*)ldsAll + kActQ + lane;                      // layer-0 B fragments
     lds_f4* bPart = (lds_f4*)((lds_q*)ldsAll + kActQ + kInQ) + w * 32 + r;
     lds_f4* bBias = (lds_f4*)((lds_q*)ldsAll + kActQ + kInQ + kPartQ) + 16 * w + h;      // tile 2w, rows 4h..
-    lds_q* bWt = (lds_q*)ldsAll + kW0Off + 4 * w * 64 + lane;        // this wave's layer-0 fragments 4w..4w+3; head: + kW0Q
+    lds_q* bWt = (lds_q*)ldsAll + kW0Off + 4 * w * 64 + lane;        // this wave's layer-0 fragments 4w..4w+3; head: + kW0Q;
+                                                                     // its four LDS-held layer-3 fragments: + kW0Q + kWoQ
     auto launder = [&]() {
         uint32_t v0 = (uint32_t)(uintptr_t)bR, v1 = (uint32_t)(uintptr_t)bW, v2 = (uint32_t)(uintptr_t)bIn,
                  v3 = (uint32_t)(uintptr_t)bPart, v4 = (uint32_t)(uintptr_t)bBias, v5 = (uint32_t)(uintptr_t)bWt;
@@ -942,6 +947,7 @@ __global__ __launch_bounds__(256, 1) void inr_ws_kernel(const InrArgs a) {
             for (int d = 0; d < RD; ++d) ring[d] = rd_frag(0, par, d);
             f32x16 accPrev;
             bf16x8 Ho[2];                                      // packed outputs of the previous pass
+            bf16x8 w3[4];                                      // layer 3: the LDS-held A fragments of tile 1, k steps 12..15
             f32x16 acc = bias_tile(l, 0);
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
@@ -952,19 +958,24 @@ __global__ __launch_bounds__(256, 1) void inr_ws_kernel(const InrArgs a) {
                 for (int ks = 0; ks < KS; ++ks) {
                     const int q = i * KS + ks;                 // position in the phase's B-fragment stream
                     if constexpr (l <= 2) mfma_a(acc, Wh[l - 1][j][ks], ring[q % RD]);             // layers 1, 2: the 256 AGPRs
-                    else mfma_v(acc, Wh[l - 1][j][ks], ring[q % RD]);                               // layer 3: 128 arch VGPRs
+                    else if (j == 1 && ks >= KS - 4) mfma_v(acc, w3[ks - (KS - 4)], ring[q % RD]);  // layer 3's four LDS-held fragments
+                    else mfma_v(acc, Wh[l - 1][j][ks], ring[q % RD]);                               // layer 3: arch VGPRs
                     if (q + RD < NP * KS) ring[q % RD] = rd_frag((q + RD) / KS >> 1, par, (q + RD) % KS);
+                    if constexpr (l == NH) { if (j == 1 && ks >= KS - 7 && ks < KS - 3) w3[ks - (KS - 7)] = __builtin_bit_cast(bf16x8, bWt[kW0Q + kWoQ + (ks - (KS - 7)) * 64]); }
                     if (i > 0) {
-                        // the previous pass's accumulator: two values per step over steps 2..9.  The compiler does not know
-                        // the asm statements are MFMAs, so the XDL-write -> VALU-read wait (8 passes + 3 states) is kept by
-                        // hand: two MFMA issues and 16 idle states in step 1's otherwise empty gap
+                        // the previous pass's accumulator, ONE value per step (two in steps 2 and 3): a v_sin next to an MFMA costs
+                        // ~16 issue cycles, two of them overflow the 24 an MFMA leaves (tools/micro/mfma_pace.hip: 709 cycles per
+                        // pass against 549 without activation).  The compiler does not know the asm statements are MFMAs, so
+                        // the XDL-write -> VALU-read wait is kept by hand: two MFMA issues, two LDS issues and 4 idle states.
                         const int pg = (i - 1) >> 1, pj = (i - 1) & 1;
-                        if (ks == 1) asm volatile("s_nop 15" : "+v"(accPrev));   // + two MFMA issues since the producer: > 8 passes + 3
-                        if (ks >= 2 && ks <= 9) { act_one(accPrev, Ho, 2 * ks - 4); act_one(accPrev, Ho, 2 * ks - 3); }
-                        if (ks == 6) wr_frag(pg, par ^ 1, pj, 0, Ho[0]);
-                        if (ks == 10) wr_frag(pg, par ^ 1, pj, 1, Ho[1]);
+                        if (ks == 1) asm volatile("s_nop 3" : "+v"(accPrev));
+                        if (ks == 2) { act_one(accPrev, Ho, 0); act_one(accPrev, Ho, 1); }
+                        if (ks == 3) { act_one(accPrev, Ho, 2); act_one(accPrev, Ho, 3); }
+                        if (ks >= 4) act_one(accPrev, Ho, ks);
+                        if (ks == 8) wr_frag(pg, par ^ 1, pj, 0, Ho[0]);
+                        if (ks == 15) wr_frag(pg, par ^ 1, pj, 1, Ho[1]);
                     }
-                    if (ks == 12 && i + 1 < NP) accNext = bias_tile(l, (i + 1) & 1);                // lands in accPrev's registers
+                    if (ks == 11 && i + 1 < NP) accNext = bias_tile(l, (i + 1) & 1);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 accPrev = acc;

@@ -22,11 +22,11 @@ d = np.diff(st[:, :, :8], axis=2)            # [block][wave][7]
 labels = ["L0+head", "bar", "hidden1(+bar)", "hidden2", "bar", "hidden3", "stage+bar"]
 for wv in range(4):
     print("wave", wv, " ".join(f"{labels[k]}={int(np.median(d[:, wv, k]))}" for k in range(7)), "round", int(np.median(st[:, wv, 7] - st[:, wv, 0])))
-if os.environ.get("MRIRT_INR_WS1"):
+if True:
   for wv in (0, 3):
     print("wave", wv, "hidden1 passes:", "prologue", int(np.median(st[:, wv, 8] - st[:, wv, 2])),
           [int(np.median(st[:, wv, 9 + k] - st[:, wv, 8 + k])) for k in range(6)], "tail", int(np.median(st[:, wv, 3] - st[:, wv, 14])))
-else:
+if False:
   for wv in range(4):
     print("v2 wave", wv, "L0+head", int(np.median(st[:, wv, 1] - st[:, wv, 0])), "H1", int(np.median(st[:, wv, 2] - st[:, wv, 1])),
           "H2", int(np.median(st[:, wv, 3] - st[:, wv, 2])), "H3", int(np.median(st[:, wv, 4] - st[:, wv, 3])), "round", int(np.median(st[:, wv, 4] - st[:, wv, 0])))
@@ -37,3 +37,11 @@ else:
   torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
   rounds_per_cu = n / 96 / 256
   print("launch", dt * 1e3, "ms; rounds per CU", rounds_per_cu, "=> wall ns per round", dt / rounds_per_cu * 1e9)
+
+import time
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(5): inr._forward(net, coords, feats, n, True, True)
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
+rounds_per_cu = n / 96 / 256
+rc = float(np.median(st[:, 0, 7] - st[:, 0, 0]))
+print("launch %.3f ms; %.1f rounds per CU => %.0f ns per round; %.0f cycles per round => %.2f GHz" % (dt * 1e3, rounds_per_cu, dt / rounds_per_cu * 1e9, rc, rc / (dt / rounds_per_cu * 1e9)))
