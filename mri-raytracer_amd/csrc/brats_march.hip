@@ -377,12 +377,15 @@ struct EmitArgs {
     const int64_t* offsets;
     float* coords;
     float4* feats;
+    float* mix;                  // C5 passes: the sample's weighted intensity (float per row), or with shading
+                                 // (intensity, gradient) as float4 per row; and its seg label when showSeg
+    uint32_t* seg;
 };
 
 // MLP inputs of the sample at index-space cell `s` -> row `row` of coords / feats (shared by the one-pass and
 // the chunked emission)
 template <bool STRICT, int LAYOUT>
-__device__ __forceinline__ void emit_row(const K1Args& a, const EmitArgs& e, const Cell& s, int64_t row) {
+__device__ __forceinline__ void emit_row(const K1Args& a, const EmitArgs& e, const Cell& s, int64_t row, float sv[4]) {
     using Mm = M<STRICT>;
     float z[4];
     Taps<LAYOUT, false> taps[4];
@@ -390,8 +393,8 @@ __device__ __forceinline__ void emit_row(const K1Args& a, const EmitArgs& e, con
     for (int m = 0; m < 4; ++m) taps[m].template issue<true>(a.vol[m], a.grid, s);      // all gathers in flight first (layouts 0..3)
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-        float v;
-        taps[m].template eval<STRICT>(s, v, nullptr);
+        taps[m].template eval<STRICT>(s, sv[m], nullptr);
+        const float v = sv[m];
         z[m] = STRICT ? Mm::divu(v - e.zmu[m], e.zsigma[m]) : (v - e.zmu[m]) * e.zsigma[m].r;
     }
 #pragma unroll
@@ -416,15 +419,17 @@ __global__ __launch_bounds__(256) void emit_samples_kernel(const K1Args a, const
     for (float t = t0; t < t1; t += a.stepSize, ++row) {
         Cell s;
         locate<STRICT>(a, ro, rd, t, s);
-        emit_row<STRICT, LAYOUT>(a, e, s, row);
+        float sv[4];
+        emit_row<STRICT, LAYOUT>(a, e, s, row, sv);
     }
 }
 
 // ---------------------------------------------------------------------------------------
 // C5, chunked and ERT-aware ("all LIVE sample points", north star): the march advances `chunk` steps per pass.
-//   plan:      every ray still alive (t < t1 and T > ert after the previous pass) counts its next <= chunk steps,
-//              takes a row range of the pass's batch (wave scan + one atomic per wave) and emits those samples' MLP
-//              inputs; the batch size stays in device memory (no host round trip);
+//   plan:      every ray still alive (t < t1 and T > ert after the previous pass) counts its next <= chunk steps and
+//              its wave takes a row range of the pass's batch (one atomic per wave); the batch size stays in device
+//              memory (no host round trip);
+//   emit:      one thread per row of the batch writes that sample's MLP inputs;
 //   classify:  mrirt's MFMA forward over that batch (inr_mlp.hip, point count read from the device word);
 //   composite: the same rays march those steps with the class stream, exactly as brats_main does (ERT tested
 //              before every step), and park their state (t, T, C) for the next pass.
@@ -432,19 +437,34 @@ __global__ __launch_bounds__(256) void emit_samples_kernel(const K1Args a, const
 // costs nothing in later passes.  The frame is the same bits as the one-pass form (the MLP is batch-position
 // invariant), which tests/test_gpu_inr_render.py holds it to.
 // ---------------------------------------------------------------------------------------
-struct C5Ray { float t, T, C0, C1, C2; uint32_t off, cnt, pad; };      // 32 B per pixel
+struct C5Ray { float t, T, C0, C1, C2; uint32_t off, cnt, pad; };      // 32 B per pixel; off = first row of the ray's WAVE
 
-template <bool STRICT, int LAYOUT>
-__global__ __launch_bounds__(256) void c5_plan_kernel(const K1Args a, const EmitArgs e, C5Ray* __restrict__ rays,
+// Row numbering of one wave's samples inside a pass's batch, shared by the plan and composite kernels (which run
+// the same pixel -> lane map): step k of the wave's rays occupies consecutive rows, in lane order, after the rows of
+// steps 0..k-1.  `step(takes)` must be called by every lane of the wave, once per k: it returns false when no lane
+// takes step k, and otherwise leaves this lane's row for that step in `row` (meaningful where takes is true).
+struct C5Rows {
+    uint32_t next, row;
+    __device__ explicit C5Rows(uint32_t waveBase) : next(waveBase), row(0u) {}
+    __device__ __forceinline__ bool step(bool takes) {
+        const uint64_t m = __ballot(takes);
+        if (m == 0) return false;
+        row = next + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        next += (uint32_t)__popcll(m);
+        return true;
+    }
+};
+
+__global__ __launch_bounds__(256) void c5_plan_kernel(const K1Args a, C5Ray* __restrict__ rays, uint2* __restrict__ rowOwner,
                                                       uint32_t* __restrict__ counter, uint32_t chunk, uint32_t first) {
     uint32_t px, py;
     int64_t oidx;
     const bool mine = map_pixel(a.map, px, py, oidx) == 1;
-    float ro[3] = { 0, 0, 0 }, rd[3] = { 0, 0, 1 }, t0 = 0.0f, t1 = 0.0f;
     C5Ray r = { 0.0f, 1.0f, a.bg[0], a.bg[1], a.bg[2], 0u, 0u, 0u };
     const int64_t pix = mine ? (int64_t)py * a.map.width + px : 0;
     uint32_t cnt = 0;
     if (mine) {
+        float ro[3], rd[3], t0, t1;
         const bool hit = setup_ray(a, px, py, ro, rd, t0, t1);
         if (first) r.t = t0; else r = rays[pix];
         if (hit && r.T > a.ert) {
@@ -452,74 +472,123 @@ __global__ __launch_bounds__(256) void c5_plan_kernel(const K1Args a, const Emit
             for (; cnt < chunk && t < t1; ++cnt) t += a.stepSize;           // the march's own running sum
         }
     }
-    // row range of this ray inside the pass's batch: exclusive scan over the wave + one atomic per wave
-    const uint32_t lane = threadIdx.x & 63u;
-    uint32_t incl = cnt;
+    // the wave's row range inside the pass's batch: one atomic per wave
+    uint32_t total = cnt;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t v = __shfl_up(incl, o);
-        if ((int)lane >= o) incl += v;
-    }
-    const uint32_t total = __shfl(incl, 63);
+    for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
     uint32_t base = 0;
-    if (lane == 0 && total != 0) base = atomicAdd(counter, total);
+    if ((threadIdx.x & 63u) == 0 && total != 0) base = atomicAdd(counter, total);
     base = __shfl(base, 0);
-    if (!mine) return;
-    r.off = base + incl - cnt;
-    r.cnt = cnt;
-    rays[pix] = r;
-    float t = r.t;
-    for (uint32_t k = 0; k < cnt; ++k, t += a.stepSize) {
+    if (mine) {
+        r.off = base;
+        r.cnt = cnt;
+        rays[pix] = r;
+    }
+    // rows in (step, lane) order: the wave's rays that take step k are neighbours in the batch, as they are in the volume
+    C5Rows rows(base);
+    for (uint32_t k = 0; rows.step(cnt > k); ++k)
+        if (cnt > k) rowOwner[rows.row] = make_uint2((uint32_t)pix, k);       // stores only: nothing waits on them
+}
+
+// One thread per ROW of the pass's batch (not per ray): the emission of a pass is ~10^6 independent samples, each
+// of them eight gathers and a few hundred flops, and a per-ray loop serialises a ray's 32 behind one another's
+// memory latency with one wave per SIMD slot to hide it (measured: 0.18 ms per pass at 512^2, 1.6 ms of a
+// 10.5 ms frame).  The rows of a wave are the same step of neighbouring rays (C5Rows), so the gathers stay as
+// coherent as the march's own and the stores are contiguous; t is rebuilt by the march's own running sum from
+// the ray's parked t (k <= chunk adds).
+template <bool STRICT, int LAYOUT, bool SHADE>
+__global__ __launch_bounds__(256) void c5_emit_kernel(const K1Args a, const EmitArgs e, const C5Ray* __restrict__ rays,
+                                                      const uint2* __restrict__ rowOwner, const uint32_t* __restrict__ counter) {
+    using Mm = M<STRICT>;
+    const uint32_t n = *counter;
+    for (uint32_t row = blockIdx.x * blockDim.x + threadIdx.x; row < n; row += gridDim.x * blockDim.x) {
+        const uint2 own = rowOwner[row];
+        const uint32_t py = own.x / a.map.width, px = own.x - py * a.map.width;
+        float ro[3], rd[3], t0, t1;
+        setup_ray(a, px, py, ro, rd, t0, t1);
+        float t = rays[own.x].t;
+        for (uint32_t k = 0; k < own.y; ++k) t += a.stepSize;
         Cell s;
         locate<STRICT>(a, ro, rd, t, s);
-        emit_row<STRICT, LAYOUT>(a, e, s, (int64_t)r.off + k);
+        float sv[4];
+        emit_row<STRICT, LAYOUT>(a, e, s, (int64_t)row, sv);
+        // what the composite pass needs of this sample besides its class: brats_rt.slang:121-141's weighted
+        // intensity (and gradient) over the enabled modalities, in the march's own order, and the seg label
+        float v = 0.0f, g[3] = { 0.0f, 0.0f, 0.0f };
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            if (a.enabled[m] != 0) {
+                if constexpr (SHADE) {
+                    Taps<LAYOUT, true> taps;
+                    float gm[3];
+                    taps.template issue<true>(a.vol[m], a.grid, s);
+                    taps.template eval<STRICT>(s, sv[m], gm);
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) g[q] = Mm::mad(gm[q], a.weight[m], g[q]);
+                }
+                v = Mm::mad(sv[m], a.weight[m], v);
+            }
+        }
+        if constexpr (SHADE) reinterpret_cast<float4*>(e.mix)[row] = make_float4(v, g[0], g[1], g[2]);
+        else e.mix[row] = v;
+        if (a.showSeg != 0) e.seg[row] = sample_label(a.labels, a.lab, s.q, a.hiLab);
     }
 }
 
-template <bool STRICT, int LAYOUT, bool SHADE>
+// The sequential part of a pass: every ray composites its <= chunk samples front to back from the per-row
+// records (class from the MLP; intensity, gradient and seg label from the emission) — no volume access, and the
+// next step's records are in flight while this step composites.
+template <bool STRICT, bool SHADE>
 __global__ __launch_bounds__(256) void c5_composite_kernel(const K1Args a, C5Ray* __restrict__ rays,
-                                                           const int16_t* __restrict__ classes) {
-    using Mm = M<STRICT>;
+                                                           const int16_t* __restrict__ classes,
+                                                           const float* __restrict__ mix, const uint32_t* __restrict__ seg) {
     uint32_t px, py;
     int64_t oidx;
     const int kind = map_pixel(a.map, px, py, oidx);
     RayState r = { a.bg[0], a.bg[1], a.bg[2], 1.0f, 0u, 0u };
+    const int64_t pix = kind == 1 ? (int64_t)py * a.map.width + px : 0;
+    C5Ray st = { 0.0f, 1.0f, 0.0f, 0.0f, 0.0f, 0u, 0u, 0u };
+    float rd[3] = { 0.0f, 0.0f, 1.0f };
     if (kind == 1) {
-        const int64_t pix = (int64_t)py * a.map.width + px;
-        C5Ray st = rays[pix];
+        st = rays[pix];
         r.C0 = st.C0; r.C1 = st.C1; r.C2 = st.C2; r.T = st.T;
-        if (st.cnt != 0) {
-            float ro[3], rd[3], t0, t1;
-            setup_ray(a, px, py, ro, rd, t0, t1);
-            float t = st.t;
-            // brats_rt.slang:117: `while (t < t1 && T > 0.01)` — t < t1 holds for these cnt steps by construction
-            for (uint32_t k = 0; k < st.cnt && r.T > a.ert; ++k) {
-                Cell s;
-                locate<STRICT>(a, ro, rd, t, s);
-                float v = 0.0f, g[3] = { 0.0f, 0.0f, 0.0f };
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    if (a.enabled[m] != 0) {
-                        Taps<LAYOUT, SHADE> taps;
-                        float sv, gm[3];
-                        taps.template issue<true>(a.vol[m], a.grid, s);
-                        taps.template eval<STRICT>(s, sv, gm);
-                        v = Mm::mad(sv, a.weight[m], v);
-                        if constexpr (SHADE) {
-#pragma unroll
-                            for (int q = 0; q < 3; ++q) g[q] = Mm::mad(gm[q], a.weight[m], g[q]);
-                        }
-                    }
-                }
-                Labels lb;
-                lb.seg = a.showSeg != 0 ? sample_label(a.labels, a.lab, s.q, a.hiLab) : 0u;
-                lb.pred = (uint32_t)(uint16_t)classes[(int64_t)st.off + k];
-                composite<STRICT, SHADE>(a, rd, lb, v, g, r);
-                t += a.stepSize;
+        if (SHADE && st.cnt != 0) { float ro[3], t0, t1; setup_ray(a, px, py, ro, rd, t0, t1); }
+    }
+    struct Rec { float v, g[3]; Labels lb; };
+    auto fetch = [&](uint32_t row, bool takes, Rec& c) {
+        c.v = 0.0f; c.g[0] = c.g[1] = c.g[2] = 0.0f; c.lb.seg = 0u; c.lb.pred = 0u;
+        if (takes) {
+            if constexpr (SHADE) {
+                const float4 m = reinterpret_cast<const float4*>(mix)[row];
+                c.v = m.x; c.g[0] = m.y; c.g[1] = m.z; c.g[2] = m.w;
+            } else {
+                c.v = mix[row];
             }
-            st.t = t; st.T = r.T; st.C0 = r.C0; st.C1 = r.C1; st.C2 = r.C2;
-            rays[pix] = st;
+            if (a.showSeg != 0) c.lb.seg = seg[row];
+            c.lb.pred = (uint32_t)(uint16_t)classes[row];
         }
+    };
+    float t = st.t;
+    bool alive = true;
+    C5Rows rows(st.off);
+    Rec cur, nxt;
+    bool more = rows.step(st.cnt > 0u);
+    fetch(rows.row, st.cnt > 0u, cur);
+    for (uint32_t k = 0; more; ++k) {
+        more = rows.step(st.cnt > k + 1u);
+        fetch(rows.row, more && st.cnt > k + 1u, nxt);
+        // brats_rt.slang:117: `while (t < t1 && T > 0.01)` — t < t1 holds for these cnt steps by construction
+        alive = alive && st.cnt > k && r.T > a.ert;
+        if (__ballot(alive) == 0) break;                 // every ray of the wave is done with this pass
+        if (alive) {
+            composite<STRICT, SHADE>(a, rd, cur.lb, cur.v, cur.g, r);
+            t += a.stepSize;
+        }
+        cur = nxt;
+    }
+    if (kind == 1 && st.cnt != 0) {
+        st.t = t; st.T = r.T; st.C0 = r.C0; st.C1 = r.C1; st.C2 = r.C2;
+        rays[pix] = st;
     }
     finish(a, kind, oidx, r);      // the frame so far (complete after the last pass); live-sample counters
 }
@@ -807,7 +876,7 @@ extern "C" int mrirt_brats_emit_samples(const MrirtBratsParams* p, const MrirtRe
     EmitArgs e;
     for (int m = 0; m < 4; ++m) { e.zmu[m] = zmu[m]; e.zsigma[m] = make_udiv(zsigma[m]); }
     for (int k = 0; k < 3; ++k) { e.dimM1[k] = (double)(p->dims[k] - 1); e.rdimM1[k] = 1.0 / e.dimM1[k]; }
-    e.offsets = offsets; e.coords = coords; e.feats = reinterpret_cast<float4*>(feats);
+    e.offsets = offsets; e.coords = coords; e.feats = reinterpret_cast<float4*>(feats); e.mix = nullptr; e.seg = nullptr;
     hipStream_t s = static_cast<hipStream_t>(stream);
     return cfg.math == MRIRT_MATH_STRICT ? launch_emit<true>(a, e, cfg.layout, s) : launch_emit<false>(a, e, cfg.layout, s);
 }
@@ -828,7 +897,7 @@ __global__ void c5_sum_kernel(const uint32_t* __restrict__ counters, uint32_t n,
     if (threadIdx.x == 0) atomicAdd(reinterpret_cast<unsigned long long*>(queries), (unsigned long long)s);
 }
 
-struct C5Scratch { uint32_t* counters; C5Ray* rays; float* coords; float* feats; int16_t* classes; int64_t cap, bytes; };
+struct C5Scratch { uint32_t* counters; C5Ray* rays; uint2* rowOwner; float* coords; float* feats; float* mix; uint32_t* seg; int16_t* classes; int64_t cap, bytes; };
 
 static int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
 
@@ -842,40 +911,44 @@ static int c5_carve(const MrirtBratsParams* p, uint32_t chunk, void* base, C5Scr
     int64_t o = 0;
     sc.counters = reinterpret_cast<uint32_t*>(b + o); o += align256((int64_t)kC5MaxPasses * 4);
     sc.rays = reinterpret_cast<C5Ray*>(b + o);        o += align256(px * (int64_t)sizeof(C5Ray));
+    sc.rowOwner = reinterpret_cast<uint2*>(b + o);    o += align256(sc.cap * 8);
     sc.coords = reinterpret_cast<float*>(b + o);      o += align256(sc.cap * 12);
     sc.feats = reinterpret_cast<float*>(b + o);       o += align256(sc.cap * 16);
+    sc.mix = reinterpret_cast<float*>(b + o);         o += align256(sc.cap * 16);
+    sc.seg = reinterpret_cast<uint32_t*>(b + o);      o += align256(sc.cap * 4);
     sc.classes = reinterpret_cast<int16_t*>(b + o);   o += align256(sc.cap * 2);
     sc.bytes = o;
     return MRIRT_OK;
 }
 
 template <bool STRICT>
-static int c5_launch_plan(const K1Args& a, const EmitArgs& e, uint32_t layout, C5Ray* rays, uint32_t* counter,
-                          uint32_t chunk, uint32_t first, hipStream_t s) {
-    if (layout > MRIRT_LAYOUT_QUAD) return MRIRT_ERR_LAYOUT;          // the C5 passes read LINEAR / BRICK / VG / QUAD grids
-    const dim3 grid(a.map.chunk * kXcds), block(a.map.blockPx == 8 ? 64 : 256);
+static int c5_launch_plan(const K1Args& a, const EmitArgs& e, uint32_t layout, bool shade, const C5Scratch& sc, uint32_t pass,
+                          uint32_t chunk, hipStream_t s) {
+    // the C5 passes read LINEAR / BRICK / VG / QUAD grids; QUAD carries no gradients
+    if (layout > MRIRT_LAYOUT_QUAD || (layout == MRIRT_LAYOUT_QUAD && shade)) return MRIRT_ERR_LAYOUT;
+    uint32_t* counter = sc.counters + pass;
+    hipLaunchKernelGGL(c5_plan_kernel, dim3(a.map.chunk * kXcds), dim3(a.map.blockPx == 8 ? 64 : 256), 0, s,
+                       a, sc.rays, sc.rowOwner, counter, chunk, pass == 0 ? 1u : 0u);
+    MRIRT_HIP(hipGetLastError());
+    const int64_t blocksWanted = (sc.cap + 255) / 256;
+    const dim3 grid((uint32_t)(blocksWanted < 4096 ? blocksWanted : 4096)), block(256);
+#define MRIRT_C5E(L, SH) hipLaunchKernelGGL((c5_emit_kernel<STRICT, L, SH>), grid, block, 0, s, a, e, sc.rays, sc.rowOwner, counter)
     switch (layout) {
-        case MRIRT_LAYOUT_LINEAR: hipLaunchKernelGGL((c5_plan_kernel<STRICT, 0>), grid, block, 0, s, a, e, rays, counter, chunk, first); break;
-        case MRIRT_LAYOUT_BRICK:  hipLaunchKernelGGL((c5_plan_kernel<STRICT, 1>), grid, block, 0, s, a, e, rays, counter, chunk, first); break;
-        case MRIRT_LAYOUT_VG:     hipLaunchKernelGGL((c5_plan_kernel<STRICT, 2>), grid, block, 0, s, a, e, rays, counter, chunk, first); break;
-        default:                  hipLaunchKernelGGL((c5_plan_kernel<STRICT, 3>), grid, block, 0, s, a, e, rays, counter, chunk, first); break;
+        case MRIRT_LAYOUT_LINEAR: if (shade) MRIRT_C5E(0, true); else MRIRT_C5E(0, false); break;
+        case MRIRT_LAYOUT_BRICK:  if (shade) MRIRT_C5E(1, true); else MRIRT_C5E(1, false); break;
+        case MRIRT_LAYOUT_VG:     if (shade) MRIRT_C5E(2, true); else MRIRT_C5E(2, false); break;
+        default:                  MRIRT_C5E(3, false); break;
     }
+#undef MRIRT_C5E
     MRIRT_HIP(hipGetLastError());
     return MRIRT_OK;
 }
 
 template <bool STRICT>
-static int c5_launch_composite(const K1Args& a, uint32_t layout, bool shade, C5Ray* rays, const int16_t* classes, hipStream_t s) {
-    if (layout > MRIRT_LAYOUT_QUAD) return MRIRT_ERR_LAYOUT;          // the C5 passes read LINEAR / BRICK / VG / QUAD grids
-    const dim3 grid(a.map.chunk * kXcds), block(a.map.blockPx == 8 ? 64 : 256);
-#define MRIRT_C5C(L, SH) hipLaunchKernelGGL((c5_composite_kernel<STRICT, L, SH>), grid, block, 0, s, a, rays, classes)
-    switch (layout) {
-        case MRIRT_LAYOUT_LINEAR: if (shade) MRIRT_C5C(0, true); else MRIRT_C5C(0, false); break;
-        case MRIRT_LAYOUT_BRICK:  if (shade) MRIRT_C5C(1, true); else MRIRT_C5C(1, false); break;
-        case MRIRT_LAYOUT_VG:     if (shade) MRIRT_C5C(2, true); else MRIRT_C5C(2, false); break;
-        default:                  if (shade) return MRIRT_ERR_LAYOUT; MRIRT_C5C(3, false); break;
-    }
-#undef MRIRT_C5C
+static int c5_launch_composite(const K1Args& a, bool shade, const C5Scratch& sc, hipStream_t s) {
+    const dim3 grid(a.map.chunk * kXcds), block(a.map.blockPx == 8 ? 64 : 256);     // the plan kernel's pixel -> lane map
+    if (shade) hipLaunchKernelGGL((c5_composite_kernel<STRICT, true>), grid, block, 0, s, a, sc.rays, sc.classes, sc.mix, sc.seg);
+    else       hipLaunchKernelGGL((c5_composite_kernel<STRICT, false>), grid, block, 0, s, a, sc.rays, sc.classes, sc.mix, sc.seg);
     MRIRT_HIP(hipGetLastError());
     return MRIRT_OK;
 }
@@ -913,20 +986,19 @@ extern "C" int mrirt_render_brats_inr(const MrirtBratsParams* p, const MrirtRend
     EmitArgs e;
     for (int m = 0; m < 4; ++m) { e.zmu[m] = zmu[m]; e.zsigma[m] = make_udiv(zsigma[m]); }
     for (int k = 0; k < 3; ++k) { e.dimM1[k] = (double)(p->dims[k] - 1); e.rdimM1[k] = 1.0 / e.dimM1[k]; }
-    e.offsets = nullptr; e.coords = sc.coords; e.feats = reinterpret_cast<float4*>(sc.feats);
+    e.offsets = nullptr; e.coords = sc.coords; e.feats = reinterpret_cast<float4*>(sc.feats); e.mix = sc.mix; e.seg = sc.seg;
     a.out = out_rgba;
     a.stats = stats_dev;
     hipStream_t s = static_cast<hipStream_t>(stream);
     MRIRT_HIP(hipMemsetAsync(sc.counters, 0, (size_t)kC5MaxPasses * 4, s));
     const bool strict = cfg.math == MRIRT_MATH_STRICT;
     for (uint32_t c = 0; c < (uint32_t)passes; ++c) {
-        rc = strict ? c5_launch_plan<true>(a, e, cfg.layout, sc.rays, sc.counters + c, chunk_steps, c == 0 ? 1u : 0u, s)
-                    : c5_launch_plan<false>(a, e, cfg.layout, sc.rays, sc.counters + c, chunk_steps, c == 0 ? 1u : 0u, s);
+        rc = strict ? c5_launch_plan<true>(a, e, cfg.layout, cfg.shade, sc, c, chunk_steps, s)
+                    : c5_launch_plan<false>(a, e, cfg.layout, cfg.shade, sc, c, chunk_steps, s);
         if (rc != MRIRT_OK) return rc;
         rc = inr_forward_dev_n(net, sc.coords, sc.feats, sc.cap, sc.counters + c, sc.classes, s);
         if (rc != MRIRT_OK) return rc;
-        rc = strict ? c5_launch_composite<true>(a, cfg.layout, cfg.shade, sc.rays, sc.classes, s)
-                    : c5_launch_composite<false>(a, cfg.layout, cfg.shade, sc.rays, sc.classes, s);
+        rc = strict ? c5_launch_composite<true>(a, cfg.shade, sc, s) : c5_launch_composite<false>(a, cfg.shade, sc, s);
         if (rc != MRIRT_OK) return rc;
     }
     if (stats_dev != nullptr) {                                               // stats_dev[2] += MLP queries of the frame
