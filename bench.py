@@ -167,7 +167,7 @@ def inr_path(dev, frames=5):
                          "frac": round(tf_frame / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
                          "basis": "live samples x flop/query over the whole frame time (plan + emit + MLP + composite)",
                          "flop_per_query": flop},
-            "mlp_kernel": {"workload": "inr_forward_kernel alone: 67.1 M resident random queries", "ms_per_launch": round(ms, 3),
+            "mlp_kernel": {"workload": "the MLP kernel alone (inr_ws_kernel, weight-stationary): 67.1 M resident random queries, 5 launches back to back", "ms_per_launch": round(ms, 3),
                            "Mqueries_s": round(nq / (ms * 1e-3) / 1e6, 1),
                            "roofline": {"bound": "mfma", "achieved": round(tflops, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
                                         "unit": "TFLOP/s", "frac": round(tflops / MFMA_BF16_PEAK_TFLOPS, 4)}}}
