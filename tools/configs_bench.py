@@ -71,5 +71,5 @@ gl = mrirt.upload_grid(lab, (n, n, n), "brick")
 img, aux = inr.render_brats_inr(p5, gv, net, zmu, zsg, labels=gl, return_aux=True)
 ms5 = timeit(lambda: inr.render_brats_inr(p5, gv, net, zmu, zsg, labels=gl), rounds=5)
 flop = 2 * sum(sizes[i] * sizes[i+1] for i in range(5))
-print(f"C5 256^3x4ch 512^2 256 steps, Fourier 103-4x256-4: {ms5:.2f} ms/frame, {aux['queries']/1e6:.1f} M MLP queries (every sample in [t0,t1)), "
+print(f"C5 256^3x4ch 512^2 256 steps, Fourier 103-4x256-4: {ms5:.2f} ms/frame, {aux['queries']/1e6:.1f} M MLP queries (live samples, ERT-aware passes), "
       f"{aux['queries']/ms5/1e3:.0f} Mquery/s end to end, {flop*aux['queries']/ms5/1e9:.0f} TFLOP/s end to end")
