@@ -237,7 +237,8 @@ typedef struct MrirtSkip {
     const float* macroUb[4];      /* per modality: mrirt_build_macro_max output, or NULL (modality unused)   */
     const uint32_t* macroSeg;     /* mrirt_build_macro_labels of gLabels (needed when showSeg)               */
     const uint32_t* macroPred;    /* ... of gPreds (needed when showPred)                                    */
-    uint32_t* mask;               /* scratch, mrirt_skip_mask_words(dims) uint32: rewritten by every launch  */
+    uint32_t* mask;               /* scratch, mrirt_skip_mask_words(dims) uint32 (8^3 macro-cell bits, then the byte
+                                     maps of the empty-radius transform): rewritten by every launch            */
 } MrirtSkip;
 int64_t mrirt_macro_cells(const uint32_t dims[3]);
 int64_t mrirt_skip_mask_words(const uint32_t dims[3]);

@@ -39,8 +39,10 @@ struct K1Args {
     const uint32_t* preds;
     const int16_t* classStream;   // C5: prediction label of sample k of ray p at classStream[rayOffsets[p] + k]
     const int64_t* rayOffsets;
-    const uint32_t* skipMask;     // exact empty-space skipping: bit per 8^3 macro cell, 1 = contributes nothing
-    uint32_t mX, mXY;             // macro cells per row / per slice
+    const uint8_t* skipDist;      // exact empty-space skipping: byte per 8^3 macro cell; 0 = may contribute, r >= 1 = this cell
+                                  // and every macro cell within Chebyshev distance r - 1 of it contribute nothing
+    uint32_t mX, mXY, mY, mZ;     // macro cells per row / per slice; rows; slices
+    uint32_t leap;                // 1: take several steps at once where skipDist allows (second level)
     void* out;
     uint64_t* stats;
     ExpConsts ec;                 // fp64 constants of the strict exp, SGPR-resident

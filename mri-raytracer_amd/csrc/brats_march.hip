@@ -86,32 +86,82 @@ __global__ __launch_bounds__(256) void brats_march_kernel(const K1Args a) {
 // a label there — skip_mask_kernel) still counts as a march step, but fetches and composites nothing:
 // the frame and the counters are the same bits as without skipping.  The flag of the lane's current
 // macro cell is cached; the mask is re-read only when the sample leaves the cell.
-struct SkipCursor { uint32_t cell; bool empty; };
+// Second level (a.leap): the map byte r of a sample's macro cell says that every macro cell within Chebyshev distance
+// r - 1 is flagged too, so the ray may move 8 (r - 1) voxels along every axis and still be in flagged cells.  When every
+// live ray of the packet is in a flagged cell, the packet takes the smallest of its lanes' budgets at
+// once: `++nLive; t += stepSize` per step — the march's own running sum and counter, no locate / fetch — and re-primes
+// the pipeline where it lands.  Every leapt sample is one the first level would have skipped: same frame, same counters.
+constexpr uint32_t kSkipDistCap = 31;  // largest radius the map records (leaps of up to 63 steps per attempt)
+
+// smallest / largest value (0..255) over the wave: eight ballots each (every lane takes part)
+__device__ __forceinline__ uint32_t wave_min8(uint32_t v) {
+    uint64_t cand = ~0ull;
+    uint32_t m = 0;
+#pragma unroll
+    for (int b = 7; b >= 0; --b) {
+        const uint64_t zero = __ballot(((v >> b) & 1u) == 0u) & cand;
+        if (zero != 0) cand = zero; else m |= 1u << b;
+    }
+    return m;
+}
+__device__ __forceinline__ uint32_t wave_max8(uint32_t v) { return 255u - wave_min8(255u - v); }
+
+// The packet's window on the distance map: the bytes of a 4 x 4 x 4 block of macro cells, one per lane, read back
+// with ds_bpermute — a cross-lane move that does not touch vmcnt, so classifying a sample never waits on (or drains)
+// the gathers in flight.  The block is moved (64 byte loads and one full wait) only when a live ray's sample leaves it,
+// every ten steps or so; it is placed with the packet's extreme cell at the trailing edge of each axis.  ds_bpermute
+// returns 0 from lanes that are switched off, which is why the skipping march keeps every lane of the wave in its
+// loops (finished rays ride along as `!alive`) instead of letting them exit.
+struct MapWindow {
+    uint32_t bytes;                  // lane l: the map byte of macro cell origin + (l & 3, (l >> 2) & 3, l >> 4)
+    uint32_t ox, oy, oz;             // wave-uniform
+    __device__ __forceinline__ void reset() { bytes = 0u; ox = oy = oz = 0x40000000u; }
+    // the map byte of the sample's macro cell; `alive` = this lane's sample matters
+    __device__ __forceinline__ uint32_t lookup(const K1Args& a, const Cell& s, const float rd[3], bool alive) {
+        const uint32_t cx = s.ix >> 3, cy = s.iy >> 3, cz = s.iz >> 3;
+        bool in = (cx - ox) < 4u && (cy - oy) < 4u && (cz - oz) < 4u;
+        if (__ballot(alive && !in) != 0) {                           // wave-uniform
+            const uint32_t lane = threadIdx.x & 63u;
+            // trailing edge per axis, by the first live lane's direction of travel (the packet's rays are near-parallel)
+            const int first = __ffsll((long long)__ballot(alive)) - 1;
+            const bool px = __shfl(rd[0], first) >= 0.0f, py = __shfl(rd[1], first) >= 0.0f, pz = __shfl(rd[2], first) >= 0.0f;
+            ox = px ? wave_min8(alive ? cx : 255u) : max(wave_max8(alive ? cx : 0u), 3u) - 3u;
+            oy = py ? wave_min8(alive ? cy : 255u) : max(wave_max8(alive ? cy : 0u), 3u) - 3u;
+            oz = pz ? wave_min8(alive ? cz : 255u) : max(wave_max8(alive ? cz : 0u), 3u) - 3u;
+            const uint32_t gx = min(ox + (lane & 3u), a.mX - 1u), gy = min(oy + ((lane >> 2) & 3u), a.mY - 1u),
+                           gz = min(oz + (lane >> 4), a.mZ - 1u);
+            uint32_t v = a.skipDist[gx + gy * a.mX + gz * a.mXY];
+            asm volatile("" : "+v"(v));                             // the wait for this load belongs inside the branch
+            bytes = v;
+            in = (cx - ox) < 4u && (cy - oy) < 4u && (cz - oz) < 4u;
+        }
+        const uint32_t li = (cx - ox) + 4u * (cy - oy) + 16u * (cz - oz);
+        const uint32_t d = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((li & 63u) << 2), (int)bytes);
+        // a ray that strays from the packet (more than 4 macro cells wide: a tiny image over a large volume) is simply
+        // not skipped: 0 = fetch and composite, always correct
+        return in ? d : 0u;
+    }
+};
 
 template <int LAYOUT, bool SHADE, int NCH, bool LABELS, bool SKIP>
 struct Stage {
     Cell s;
     Taps<LAYOUT, SHADE> taps[NCH];
     Labels lb;
+    uint32_t dist;                   // SKIP: the map byte of the sample's macro cell (0 = fetch and composite)
     bool empty;
-    __device__ __forceinline__ void classify(const K1Args& a, SkipCursor& k) {
-        if constexpr (SKIP) {
-            const uint32_t cell = (s.ix >> 3) + (s.iy >> 3) * a.mX + (s.iz >> 3) * a.mXY;
-            if (cell != k.cell) {
-                k.cell = cell;
-                k.empty = ((a.skipMask[cell >> 5] >> (cell & 31u)) & 1u) != 0;
-            }
-            empty = k.empty;
-        } else {
-            empty = false;
-        }
-    }
+    __device__ __forceinline__ void classify(uint32_t d) { dist = d; empty = SKIP && d != 0u; }
     // streamRow / streamValid: C5's class stream (one class per sample of the ray); the fetch of step k+1 is
     // speculative, so it is made only when that sample exists (t_next < t1)
     __device__ __forceinline__ void issue(const K1Args& a, const WaveGrid<LAYOUT>& wg, int64_t streamRow = 0, bool streamValid = true) {
-        if (SKIP && empty) return;
+        // SKIP: a sample that fetches nothing still ISSUES its gathers, all at cell (0,0,0) — loads inside a branch would
+        // make every later s_waitcnt vmcnt conservative (the counter retires in order; a load that may or may not have
+        // been issued cannot be counted past), i.e. vmcnt(0) everywhere and no pipelining at all: measured 1.8x on a
+        // dense volume.  Lanes on one line cost one tag look-up per quad.
+        Cell c0 = s;
+        if (SKIP && empty) { c0.ix = 0u; c0.iy = 0u; c0.iz = 0u; }
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) taps[c].template issue<false>(wg.base(a.vol[a.chan[c]]), wg.dims(), s);   // grid (copy) < 4 GiB (launch())
+        for (int c = 0; c < NCH; ++c) taps[c].template issue<false>(wg.base(a.vol[a.chan[c]]), wg.dims(), c0);   // grid (copy) < 4 GiB (launch())
         if constexpr (LABELS) {
             if (a.classStream != nullptr && !streamValid) { lb.seg = a.showSeg != 0 ? sample_label(a.labels, a.lab, s.q, a.hiLab) : 0u; lb.pred = 0u; }
             else fetch_labels(a, s, lb, streamRow);
@@ -149,6 +199,78 @@ struct Stage {
     }
 };
 
+// The skipping march (exact empty-space skipping, both levels).  Every lane of the wave stays in the loops; a ray that
+// has finished (or never marched) rides along as `!alive`: it counts as empty with unlimited room, issues its gathers
+// at cell 0 and composites nothing.  The march alternates between
+//   an EMPTY run  — every live ray's sample is flagged: nothing is fetched; with a.leap the packet takes the smallest of
+//                   its lanes' budgets (from the map byte: 8 (r - 1) - 1 voxels of room along every axis) in one go; and
+//   a DENSE run   — the two-stage pipeline of the plain kernel, gathers always issued (flagged samples at cell 0), left
+//                   when the whole packet's next sample is flagged.
+// Per step the arithmetic that decides anything (t, the while-condition, the compositing) is the plain kernel's.
+// The class stream of C5 is not supported here (the launchers never combine the two).
+template <bool STRICT, int LAYOUT, bool SHADE, int NCH, bool GAMMA1, bool LABELS>
+__device__ __forceinline__ void march_skip(const K1Args& a, const WaveGrid<LAYOUT>& wg, const float ro[3], const float rd[3],
+                                           float t0, float t1, bool marches, RayState& r) {
+    bool alive = marches;
+    if (__ballot(alive) == 0) return;
+    float t = t0;
+    Stage<LAYOUT, SHADE, NCH, LABELS, true> A, B;
+    MapWindow win;
+    win.reset();
+    // steps per voxel of room along the fastest axis (index-space advance per step = rd / voxelSize * stepSize)
+    const float stepsPerVoxel = __builtin_amdgcn_rcpf(fmaxf(fmaxf(fabsf(rd[0] * a.vox[0].r), fabsf(rd[1] * a.vox[1].r)),
+                                                            fabsf(rd[2] * a.vox[2].r)) * a.stepSize);
+    locate<STRICT>(a, ro, rd, t, A.s);
+    uint32_t dA = win.lookup(a, A.s, rd, alive);
+    while (true) {
+        // invariant: A.s / dA describe the sample at t; for live rays (t < t1 && T > ert) holds
+        if (__ballot(alive && dA == 0u) == 0) {                      // every live ray's sample is flagged
+            uint32_t n = 1u;
+            if (a.leap != 0u) {
+                // samples 0 (this one) .. m stay within 8 (dA - 1) - 1 voxels of it along every axis: m + 1 steps are free
+                const uint32_t nl = !alive ? 63u : dA >= 2u ? min((uint32_t)((float)(8u * (dA - 1u) - 1u) * stepsPerVoxel), 62u) + 1u : 1u;
+                n = wave_min8(nl);
+            }
+            for (uint32_t i = 0; i < n; ++i) {                       // wave-uniform trip count
+                const bool go = alive && t < t1;
+                r.nLive += go ? 1u : 0u;
+                t = go ? t + a.stepSize : t;
+            }
+            alive = alive && t < t1;
+            if (__ballot(alive) == 0) break;
+            locate<STRICT>(a, ro, rd, t, A.s);
+            dA = win.lookup(a, A.s, rd, alive);
+            continue;
+        }
+        A.classify(alive ? dA : 1u);
+        A.issue(a, wg);
+        bool leave = false;
+        while (true) {
+            float tn = t + a.stepSize;
+            locate<STRICT>(a, ro, rd, tn, B.s);
+            uint32_t dB = win.lookup(a, B.s, rd, alive);
+            B.classify(alive ? dB : 1u);
+            leave = __ballot(alive && dB == 0u) == 0;                // the packet's next sample is flagged throughout
+            B.issue(a, wg);                                          // (issued regardless: see Stage::issue)
+            if (alive) A.template consume<STRICT, GAMMA1>(a, rd, r);
+            t = alive ? tn : t;
+            alive = alive && t < t1 && r.T > a.ert;
+            if (leave || __ballot(alive) == 0) { A.s = B.s; dA = dB; break; }
+            tn = t + a.stepSize;
+            locate<STRICT>(a, ro, rd, tn, A.s);
+            dA = win.lookup(a, A.s, rd, alive);
+            A.classify(alive ? dA : 1u);
+            leave = __ballot(alive && dA == 0u) == 0;
+            A.issue(a, wg);
+            if (alive) B.template consume<STRICT, GAMMA1>(a, rd, r);
+            t = alive ? tn : t;
+            alive = alive && t < t1 && r.T > a.ert;
+            if (leave || __ballot(alive) == 0) break;                // A.s / dA already describe the sample at t
+        }
+        if (__ballot(alive) == 0) break;
+    }
+}
+
 template <bool STRICT, int LAYOUT, bool SHADE, int NCH, bool GAMMA1, bool LABELS, bool SKIP>
 __global__ __launch_bounds__(256, (LABELS || SKIP) ? 3 : 4) void brats_march_pipe_kernel(const K1Args a) {
     uint32_t px, py;
@@ -160,27 +282,28 @@ __global__ __launch_bounds__(256, (LABELS || SKIP) ? 3 : 4) void brats_march_pip
     WaveGrid<LAYOUT> wg;
     if constexpr (LAYOUT == 4) wg.f = a.vga.ax[vga_pick_axis(a, ro, rd, marches)];      // every lane votes: outside the branch
     else wg.g = &a.grid;
-    if (marches) {
+    if constexpr (SKIP) {
+        march_skip<STRICT, LAYOUT, SHADE, NCH, GAMMA1, LABELS>(a, wg, ro, rd, t0, t1, marches, r);
+    } else if (marches) {
         float t = t0;
         Stage<LAYOUT, SHADE, NCH, LABELS, SKIP> A, B;
-        SkipCursor cur = { 0xffffffffu, false };
         int64_t row = 0;                                             // C5: next row of this ray in the class stream
         if constexpr (LABELS) { if (a.classStream != nullptr) row = a.rayOffsets[(int64_t)py * a.map.width + px]; }
         locate<STRICT>(a, ro, rd, t, A.s);
-        A.classify(a, cur);
+        A.classify(0u);
         A.issue(a, wg, row++, true);
         while (true) {
             // invariant: stage A holds the sample at t, and (t < t1 && T > ert) holds
             float tn = t + a.stepSize;
             locate<STRICT>(a, ro, rd, tn, B.s);
-            B.classify(a, cur);
+            B.classify(0u);
             B.issue(a, wg, row++, tn < t1);                       // speculative next step
             A.template consume<STRICT, GAMMA1>(a, rd, r);
             t = tn;
             if (!(t < t1 && r.T > a.ert)) break;
             tn = t + a.stepSize;
             locate<STRICT>(a, ro, rd, tn, A.s);
-            A.classify(a, cur);
+            A.classify(0u);
             A.issue(a, wg, row++, tn < t1);
             B.template consume<STRICT, GAMMA1>(a, rd, r);
             t = tn;
@@ -286,7 +409,7 @@ static int launch_pipe(const K1Args& a, hipStream_t s) {
     // ... and drop the label state when no overlay is shown (STRICT only: FAST already fits)
     const bool overlays = a.showSeg != 0 || a.showPred != 0;
     // SKIP exists for the gamma == 1 STRICT kernels and for FAST; any other launch ignores the mask (still exact)
-    const bool skip = a.skipMask != nullptr;
+    const bool skip = a.skipDist != nullptr;
     if (STRICT && a.gamma == 1.0f && !overlays) {
         if (skip) hipLaunchKernelGGL((brats_march_pipe_kernel<STRICT, LAYOUT, SHADE, NCH, STRICT, !STRICT, true>), grid, block, 0, s, a);
         else      hipLaunchKernelGGL((brats_march_pipe_kernel<STRICT, LAYOUT, SHADE, NCH, STRICT, !STRICT, false>), grid, block, 0, s, a);
@@ -306,7 +429,7 @@ template <bool STRICT, int LAYOUT, bool SHADE>
 static int launch(const K1Args& a, bool pipe, hipStream_t s) {
     if constexpr (LAYOUT == 2) {                      // VG: 8 float4 per modality per stage -> one modality; more: rolling pairs
         if (pipe && a.nch == 1 && !a.grid.wide) return launch_pipe<STRICT, 2, SHADE, 1>(a, s);
-        if (pipe && !a.grid.wide && a.skipMask == nullptr && a.showSeg == 0 && a.showPred == 0) {   // (with overlays the generic kernel measured faster)
+        if (pipe && !a.grid.wide && a.skipDist == nullptr && a.showSeg == 0 && a.showPred == 0) {   // (with overlays the generic kernel measured faster)
             switch (a.nch) {
                 case 2: return launch_roll<STRICT, 2, SHADE, 2>(a, s);
                 case 3: return launch_roll<STRICT, 2, SHADE, 3>(a, s);
@@ -317,7 +440,7 @@ static int launch(const K1Args& a, bool pipe, hipStream_t s) {
     }
     if constexpr (LAYOUT == 4) {                      // VGA: as VG; every copy is < 4 GiB by construction (prepare())
         if (pipe && a.nch == 1) return launch_pipe<STRICT, 4, SHADE, 1>(a, s);
-        if (pipe && a.skipMask == nullptr && a.showSeg == 0 && a.showPred == 0) {
+        if (pipe && a.skipDist == nullptr && a.showSeg == 0 && a.showPred == 0) {
             switch (a.nch) {
                 case 2: return launch_roll<STRICT, 4, SHADE, 2>(a, s);
                 case 3: return launch_roll<STRICT, 4, SHADE, 3>(a, s);
@@ -692,7 +815,7 @@ static int prepare(const MrirtBratsParams* p, const MrirtRenderExt* ext, const v
     a.labels = static_cast<const uint32_t*>(labels);
     a.preds = static_cast<const uint32_t*>(preds);
     a.classStream = nullptr; a.rayOffsets = nullptr;
-    a.skipMask = nullptr; a.mX = a.mXY = 0;
+    a.skipDist = nullptr; a.mX = a.mXY = a.mY = a.mZ = 0; a.leap = 0;
     fill_exp_consts(a.ec);
     a.expSmall = (fabsf(p->intensityAlpha * p->stepSize) <= 0.125f) ? 1u : 0u;   // val is in [0, 1]
     a.out = nullptr; a.stats = nullptr;
@@ -743,6 +866,30 @@ __global__ __launch_bounds__(256) void skip_mask_kernel(const SkipArgs k) {
     }
 }
 
+// The distance map from the mask, one axis at a time (box emptiness is separable).  r(c) = largest r <= cap such that
+// every in-grid cell within r - 1 of c along the axes done so far has the property; cells outside the grid never hold a
+// sample, so they do not constrain.  Pass x reads the bits, passes y and z read the previous pass's bytes.
+template <int AXIS>
+__global__ __launch_bounds__(256) void skip_dist_kernel(const uint32_t* __restrict__ mask, const uint8_t* __restrict__ prev,
+                                                        uint8_t* __restrict__ next, uint32_t mx, uint32_t my, uint32_t mz) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= mx * my * mz) return;
+    const uint32_t xyz[3] = { c % mx, (c / mx) % my, c / (mx * my) }, ext[3] = { mx, my, mz };
+    const uint32_t stride = AXIS == 0 ? 1u : AXIS == 1 ? mx : mx * my;
+    auto at = [&](uint32_t cell) -> uint32_t {
+        if constexpr (AXIS == 0) return ((mask[cell >> 5] >> (cell & 31u)) & 1u) != 0 ? kSkipDistCap : 0u;
+        else return prev[cell];
+    };
+    // m = smallest value within distance r of c; radius r + 1 is good when m >= r + 1
+    uint32_t m = at(c), r = 0;
+    while (r < m && r < kSkipDistCap) {
+        ++r;
+        if (xyz[AXIS] >= r) m = min(m, at(c - r * stride));
+        if (xyz[AXIS] + r < ext[AXIS]) m = min(m, at(c + r * stride));
+    }
+    next[c] = (uint8_t)r;
+}
+
 }  // namespace mrirt
 
 using namespace mrirt;
@@ -787,6 +934,7 @@ extern "C" int mrirt_render_brats_skip(const MrirtBratsParams* p, const MrirtRen
     // window width and gamma (pow(0, g) = 0), non-negative weights (monotone sum), a bound for every enabled
     // modality and a label summary for every shown overlay.  Otherwise: the ordinary launch.
     bool ok = skip->mask != nullptr && p->ww > 0.0f && p->gamma > 0.0f && a.nch >= 1;
+    for (int k = 0; k < 3; ++k) ok = ok && (p->dims[k] + 7) / 8 <= 256;   // macro coordinates travel through 8-bit wave reductions
     for (uint32_t c = 0; c < a.nch && ok; ++c)
         ok = skip->macroUb[a.chan[c]] != nullptr && a.weight[a.chan[c]] >= 0.0f;
     if (p->showSeg != 0 && !skip->macroSeg) ok = false;
@@ -804,7 +952,15 @@ extern "C" int mrirt_render_brats_skip(const MrirtBratsParams* p, const MrirtRen
         if (cfg.math == MRIRT_MATH_STRICT) hipLaunchKernelGGL(skip_mask_kernel<true>, grid, block, 0, s, k);
         else                               hipLaunchKernelGGL(skip_mask_kernel<false>, grid, block, 0, s, k);
         MRIRT_HIP(hipGetLastError());
-        a.skipMask = skip->mask; a.mX = mx; a.mXY = mx * my;
+        // bits -> distance bytes; the two byte maps follow the bit words in the same scratch (mrirt_skip_mask_words)
+        uint8_t* mapA = reinterpret_cast<uint8_t*>(skip->mask + ((k.cells + 63u) / 64u) * 2u);
+        uint8_t* mapB = mapA + ((k.cells + 3u) & ~3u);
+        hipLaunchKernelGGL(skip_dist_kernel<0>, grid, block, 0, s, skip->mask, (const uint8_t*)nullptr, mapA, mx, my, mz);
+        hipLaunchKernelGGL(skip_dist_kernel<1>, grid, block, 0, s, skip->mask, (const uint8_t*)mapA, mapB, mx, my, mz);
+        hipLaunchKernelGGL(skip_dist_kernel<2>, grid, block, 0, s, skip->mask, (const uint8_t*)mapB, mapA, mx, my, mz);
+        MRIRT_HIP(hipGetLastError());
+        a.skipDist = mapA; a.mX = mx; a.mXY = mx * my; a.mY = my; a.mZ = mz;
+        a.leap = (a.debugFlags & 2u) == 0u ? 1u : 0u;                 // kernelVariant bit 8: first level only (A/B timing)
     }
     return cfg.math == MRIRT_MATH_STRICT ? launch_layout<true>(a, cfg.layout, cfg.shade, cfg.pipe, s)
                                          : launch_layout<false>(a, cfg.layout, cfg.shade, cfg.pipe, s);

@@ -271,7 +271,11 @@ extern "C" int64_t mrirt_macro_cells(const uint32_t dims[3]) {
 }
 
 extern "C" int64_t mrirt_skip_mask_words(const uint32_t dims[3]) {      // whole wave ballots: 2 words per 64 cells
-    return ((mrirt_macro_cells(dims) + 63) / 64) * 2;
+    if (!dims) return 0;
+    // the 8^3 macro-cell bits, then two byte maps (one byte per macro cell, padded to words): the distance map and the
+    // scratch of its separable passes
+    const int64_t cells = mrirt_macro_cells(dims);
+    return ((cells + 63) / 64) * 2 + 2 * ((cells + 3) / 4);
 }
 
 static int macro_common(const void* lin, void* out, const uint32_t dims[3], bool labels, void* stream) {

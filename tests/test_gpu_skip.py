@@ -143,3 +143,65 @@ def test_skip_with_tile_sharding():
     for r, t in enumerate(parts):
         gathered[r, :t.shape[0]] = t
     assert torch.equal(mrirt.detile(gathered, image, image, tile, world), whole)
+
+
+@pytest.mark.parametrize("layout,shade", [("vga", True), ("vg", True), ("quad", False)])
+@pytest.mark.parametrize("math", ["strict", "fast"])
+def test_second_level_leaps_are_bit_identical(layout, shade, math):
+    """32^3 super cells: rays cross wide empty regions in leaps (the march's own `t += dt` chain and live counter, no
+    per-step work).  A small off-centre blob in a 200 x 168 x 136 box (sides that are not multiples of 32) leaves most
+    super cells leapable; frames and counters must equal the plain launch and the first-level-only launch
+    (kernelVariant bit 8), for cameras inside and outside the box and for a step longer than a macro cell."""
+    import torch
+    import mrirt
+    from mrirt import render, synth
+    dims = (200, 168, 136)
+    z, y, x = np.meshgrid(*[np.arange(d, dtype=np.float32) for d in dims[::-1]], indexing="ij")
+    r2 = ((x - 140) / 30) ** 2 + ((y - 60) / 24) ** 2 + ((z - 90) / 20) ** 2
+    rng = np.random.default_rng(9)
+    vol = np.where(r2 < 1, 0.3 + 0.6 * rng.random(r2.shape, dtype=np.float32), 0).astype(np.float32).reshape(-1)
+    grid = mrirt.upload_grid(vol, dims, layout)
+    for steps, dist in ((320, 2.4), (320, 0.35), (40, 2.4)):
+        p = synth.brats_scene(max(dims), 192, steps, channels=1, intensity_alpha=5.0, dims=dims)
+        p["eye"] = (np.asarray(p["eye"], np.float32) * np.float32(dist / 2.4)).astype(np.float32)
+        p["wl"], p["ww"] = np.float32(0.45), np.float32(0.7)
+        ext = dict(synth.SHADE_EXT) if shade else {}
+        ext.update(layout=layout, math=math)
+        plain, st0 = mrirt.render_brats(p, [grid], ext=ext, stats=True)
+        l1, st1 = mrirt.render_brats(p, [grid], ext=dict(ext, kernelVariant=256), stats=True, skip=True)
+        l2, st2 = mrirt.render_brats(p, [grid], ext=ext, stats=True, skip=True)
+        assert torch.equal(plain, l1) and torch.equal(plain, l2)
+        assert st0 == st1 == st2
+        assert st0["live_samples"] > 10 * max(st0["shaded_samples"], 1) or not shade
+    # the distance map follows the mask words: check it against a brute-force Chebyshev transform of the mask
+    import ctypes as C
+    from mrirt import _lib
+    d = (C.c_uint32 * 3)(*dims)
+    cells = int(_lib.lib().mrirt_macro_cells(d))
+    macro_words = ((cells + 63) // 64) * 2
+    raw = render._last_skip_mask.cpu().numpy().view(np.uint32)
+    mx, my, mz = [(v + 7) // 8 for v in dims]
+    empty = np.unpackbits(raw[:macro_words].view(np.uint8), bitorder="little")[:cells].reshape(mz, my, mx).astype(bool)
+    got = raw[macro_words:].view(np.uint8)[:cells].reshape(mz, my, mx)
+    want = np.zeros_like(got)
+    pad = 31
+    big = np.ones((mz + 2 * pad, my + 2 * pad, mx + 2 * pad), bool)          # outside the grid: no constraint
+    big[pad:pad + mz, pad:pad + my, pad:pad + mx] = empty
+    ok = np.ones_like(empty)
+    for r in range(1, 32):
+        # radius r: every cell within r - 1 is empty
+        k = r - 1
+        box = np.ones_like(empty)
+        for dz in range(-k, k + 1):
+            for dy in range(-k, k + 1):
+                sl = big[pad + dz:pad + dz + mz, pad + dy:pad + dy + my]
+                run = np.ones_like(empty)
+                for dx in range(-k, k + 1):
+                    run &= sl[:, :, pad + dx:pad + dx + mx]
+                box &= run
+        ok &= box
+        want[ok] = r
+        if not ok.any():
+            break
+    assert np.array_equal(got, want)
+    assert (got >= 2).mean() > 0.3

@@ -20,7 +20,7 @@ vol += 0.04 * rng.random((n, n, n), dtype=np.float32)
 vol[r > 1.0] = 0.0
 vol = np.ascontiguousarray(vol).reshape(-1)
 print(f"occupied voxels: {float((vol > 0).mean()):.3f}")
-for layout, shade in (("vg", True), ("quad", False)):
+for layout, shade in (("vga", True), ("vg", True), ("quad", False)):
     g = mrirt.upload_grid(vol, (n, n, n), layout)
     for alpha in (16.0, 2.0):
         p = synth.brats_scene(n, image, steps, channels=1, intensity_alpha=alpha)
@@ -28,17 +28,20 @@ for layout, shade in (("vg", True), ("quad", False)):
         ext.update(layout=layout)
         out = torch.empty((image, image, 4), device="cuda")
         res = {}
-        for skip in (False, True):
+        for mode in ("plain", "level1", "skip"):            # level1: 8^3 macro cells only (kernelVariant bit 8); skip: + 32^3 leaps
+            e = dict(ext, kernelVariant=256) if mode == "level1" else ext
+            skip = mode != "plain"
             for _ in range(3):
-                mrirt.render_brats(p, [g], out=out, ext=ext, skip=skip)
+                mrirt.render_brats(p, [g], out=out, ext=e, skip=skip)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(10):
-                mrirt.render_brats(p, [g], out=out, ext=ext, skip=skip)
+                mrirt.render_brats(p, [g], out=out, ext=e, skip=skip)
             e1.record(); torch.cuda.synchronize()
-            _, st = mrirt.render_brats(p, [g], out=out, ext=ext, skip=skip, stats=True)
-            res[skip] = (e0.elapsed_time(e1) / 10, out.clone(), st)
-        same = torch.equal(res[False][1], res[True][1]) and res[False][2] == res[True][2]
-        st = res[True][2]
-        print(f"{n}^3 {image}^2 x {steps}  {layout:4s} shade={int(shade)} alpha={alpha:4.1f}: plain {res[False][0]:.3f} ms, skip {res[True][0]:.3f} ms "
-              f"({res[False][0] / res[True][0]:.2f}x), live {st['live_samples'] / 1e6:.1f} M / shaded {st['shaded_samples'] / 1e6:.1f} M, identical={same}")
+            _, st = mrirt.render_brats(p, [g], out=out, ext=e, skip=skip, stats=True)
+            res[mode] = (e0.elapsed_time(e1) / 10, out.clone(), st)
+        same = all(torch.equal(res["plain"][1], res[m][1]) and res["plain"][2] == res[m][2] for m in ("level1", "skip"))
+        st = res["skip"][2]
+        print(f"{n}^3 {image}^2 x {steps}  {layout:4s} shade={int(shade)} alpha={alpha:4.1f}: plain {res['plain'][0]:.3f} ms, "
+              f"8^3 cells {res['level1'][0]:.3f} ms, + 32^3 leaps {res['skip'][0]:.3f} ms ({res['plain'][0] / res['skip'][0]:.2f}x), "
+              f"live {st['live_samples'] / 1e6:.1f} M / shaded {st['shaded_samples'] / 1e6:.1f} M, identical={same}", flush=True)
