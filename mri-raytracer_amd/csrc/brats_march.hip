@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void brats_march_kernel(const K1Args a) {
 // live ray of the packet is in a flagged cell, the packet takes the smallest of its lanes' budgets at
 // once: `++nLive; t += stepSize` per step — the march's own running sum and counter, no locate / fetch — and re-primes
 // the pipeline where it lands.  Every leapt sample is one the first level would have skipped: same frame, same counters.
-constexpr uint32_t kSkipDistCap = 31;  // largest radius the map records (leaps of up to 63 steps per attempt)
+constexpr uint32_t kSkipDistCap = 31;  // largest radius the map records: 239 voxels of room
 
 // smallest / largest value (0..255) over the wave: eight ballots each (every lane takes part)
 __device__ __forceinline__ uint32_t wave_min8(uint32_t v) {
@@ -228,7 +228,7 @@ __device__ __forceinline__ void march_skip(const K1Args& a, const WaveGrid<LAYOU
             uint32_t n = 1u;
             if (a.leap != 0u) {
                 // samples 0 (this one) .. m stay within 8 (dA - 1) - 1 voxels of it along every axis: m + 1 steps are free
-                const uint32_t nl = !alive ? 63u : dA >= 2u ? min((uint32_t)((float)(8u * (dA - 1u) - 1u) * stepsPerVoxel), 62u) + 1u : 1u;
+                const uint32_t nl = !alive ? 255u : dA >= 2u ? min((uint32_t)((float)(8u * (dA - 1u) - 1u) * stepsPerVoxel), 254u) + 1u : 1u;
                 n = wave_min8(nl);
             }
             for (uint32_t i = 0; i < n; ++i) {                       // wave-uniform trip count

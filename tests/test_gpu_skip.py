@@ -148,10 +148,11 @@ def test_skip_with_tile_sharding():
 @pytest.mark.parametrize("layout,shade", [("vga", True), ("vg", True), ("quad", False)])
 @pytest.mark.parametrize("math", ["strict", "fast"])
 def test_second_level_leaps_are_bit_identical(layout, shade, math):
-    """32^3 super cells: rays cross wide empty regions in leaps (the march's own `t += dt` chain and live counter, no
-    per-step work).  A small off-centre blob in a 200 x 168 x 136 box (sides that are not multiples of 32) leaves most
-    super cells leapable; frames and counters must equal the plain launch and the first-level-only launch
-    (kernelVariant bit 8), for cameras inside and outside the box and for a step longer than a macro cell."""
+    """Second level: the packet crosses wide empty regions in leaps sized by the empty-radius map (the march's own
+    `t += dt` chain and live counter, no per-step work).  A small off-centre blob in a 200 x 168 x 136 box (sides that
+    are not multiples of 8) leaves most of the box leapable; frames and counters must equal the plain launch and the
+    step-by-step launch (kernelVariant bit 8), for cameras inside and outside the box and for a step longer than a
+    macro cell; the map itself is checked against a brute-force Chebyshev transform of the mask."""
     import torch
     import mrirt
     from mrirt import render, synth

@@ -28,7 +28,7 @@ for layout, shade in (("vga", True), ("vg", True), ("quad", False)):
         ext.update(layout=layout)
         out = torch.empty((image, image, 4), device="cuda")
         res = {}
-        for mode in ("plain", "level1", "skip"):            # level1: 8^3 macro cells only (kernelVariant bit 8); skip: + 32^3 leaps
+        for mode in ("plain", "level1", "skip"):            # level1: one step at a time (kernelVariant bit 8); skip: + packet leaps
             e = dict(ext, kernelVariant=256) if mode == "level1" else ext
             skip = mode != "plain"
             for _ in range(3):
@@ -43,5 +43,5 @@ for layout, shade in (("vga", True), ("vg", True), ("quad", False)):
         same = all(torch.equal(res["plain"][1], res[m][1]) and res["plain"][2] == res[m][2] for m in ("level1", "skip"))
         st = res["skip"][2]
         print(f"{n}^3 {image}^2 x {steps}  {layout:4s} shade={int(shade)} alpha={alpha:4.1f}: plain {res['plain'][0]:.3f} ms, "
-              f"8^3 cells {res['level1'][0]:.3f} ms, + 32^3 leaps {res['skip'][0]:.3f} ms ({res['plain'][0] / res['skip'][0]:.2f}x), "
+              f"8^3 cells, step by step {res['level1'][0]:.3f} ms, + distance-map leaps {res['skip'][0]:.3f} ms ({res['plain'][0] / res['skip'][0]:.2f}x), "
               f"live {st['live_samples'] / 1e6:.1f} M / shaded {st['shaded_samples'] / 1e6:.1f} M, identical={same}", flush=True)
