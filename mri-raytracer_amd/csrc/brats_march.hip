@@ -896,7 +896,9 @@ using namespace mrirt;
 
 // kernelVariant toggles (experiments; 0 = library default):
 //   bit 0: row-major instead of Morton lane order      bit 1: 256-thread instead of 64-thread workgroups
-//   bit 2: no software pipelining
+//   bit 2: no software pipelining                      bits 3-5: XCD band height (prepare())
+//   bit 6: the LDS-staged kernel of brats_slab.hip     bit 7: ... counts its LDS-served samples in stats[1]
+//   bit 8: skipping one step at a time (no leaps); in the slab kernel: count ring misses
 extern "C" int mrirt_render_brats_ex(const MrirtBratsParams* p, const MrirtRenderExt* ext,
                                      const void* const vol[4], const void* labels, const void* preds,
                                      void* out_rgba, int64_t pitch_px, uint64_t* stats_dev, void* stream) {
@@ -1062,7 +1064,7 @@ static int c5_carve(const MrirtBratsParams* p, uint32_t chunk, void* base, C5Scr
     const int64_t px = (int64_t)p->imageSize[0] * p->imageSize[1];
     if (px <= 0) return MRIRT_ERR_DIMS;
     sc.cap = px * chunk;
-    if (sc.cap >= ((int64_t)1 << 32)) return MRIRT_ERR_ARG;              // 32-bit row offsets per pass
+    if (sc.cap >= ((int64_t)1 << 32) - ((int64_t)1 << 21)) return MRIRT_ERR_ARG;   // 32-bit row numbers per pass (+ one grid stride of headroom)
     char* b = static_cast<char*>(base);
     int64_t o = 0;
     sc.counters = reinterpret_cast<uint32_t*>(b + o); o += align256((int64_t)kC5MaxPasses * 4);

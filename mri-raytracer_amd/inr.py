@@ -261,7 +261,8 @@ def render_brats_inr(params, intensities, net: PackedMLP, zmu, zsigma, labels=No
     _lib.check(lib.mrirt_render_brats_stream(C.byref(P), C.byref(E), vp, _ptr(lab), _ptr(classes), _ptr(offsets),
                                              _ptr(o), pitch, _ptr(st), s), "mrirt_render_brats_stream")
     if return_aux:
-        return o, dict(queries=total, live_samples=int(st.cpu()[0]), classes=classes, offsets=offsets, coords=coords,
+        c = st.cpu()
+        return o, dict(queries=total, live_samples=int(c[0]), shaded_samples=int(c[1]), classes=classes, offsets=offsets, coords=coords,
                        feats=feats, counts=counts)
     return o
 

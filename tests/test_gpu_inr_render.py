@@ -161,6 +161,18 @@ def test_c5_chunked_is_bit_identical_to_one_pass(setup, kind):
     assert torch.equal(img2, ref)
     fast = inr.render_brats_inr(p, grids, net, s["zmu"], s["zsg"], labels=gl, ext=dict(math="fast"), chunk_steps=16)
     assert float((fast - ref).abs().max()) < 0.3 and float((fast - ref).abs().mean()) < 2e-3
+    # gradient shading (VG voxels: the emission pass also records the sample's gradient) and bricked fp32 voxels
+    from mrirt import synth
+    vg = [mrirt.upload_grid(v, dims, "vg") for v in s["vols"]]
+    ext = dict(synth.SHADE_EXT, layout="vg")
+    ref_sh, ash = inr.render_brats_inr(p, vg, net, s["zmu"], s["zsg"], labels=gl, ext=ext, return_aux=True, one_pass=True)
+    assert not torch.equal(ref_sh, ref)
+    for chunk in (3, 32):
+        img, a = inr.render_brats_inr(p, vg, net, s["zmu"], s["zsg"], labels=gl, ext=ext, return_aux=True, chunk_steps=chunk)
+        assert torch.equal(img, ref_sh), chunk
+        assert a["live_samples"] == ash["live_samples"] and a["shaded_samples"] == ash["shaded_samples"]
+    br = [mrirt.upload_grid(v, dims, "brick") for v in s["vols"]]
+    assert torch.equal(inr.render_brats_inr(p, br, net, s["zmu"], s["zsg"], labels=gl, chunk_steps=7), ref)
 
 
 def test_c5_as_named_siren_4x256_512x512_256_samples():
