@@ -578,22 +578,16 @@ struct C5Rows {
     }
 };
 
-__global__ __launch_bounds__(256) void c5_plan_kernel(const K1Args a, C5Ray* __restrict__ rays, uint2* __restrict__ rowOwner,
-                                                      uint32_t* __restrict__ counter, uint32_t chunk, uint32_t first) {
-    uint32_t px, py;
-    int64_t oidx;
-    const bool mine = map_pixel(a.map, px, py, oidx) == 1;
-    C5Ray r = { 0.0f, 1.0f, a.bg[0], a.bg[1], a.bg[2], 0u, 0u, 0u };
-    const int64_t pix = mine ? (int64_t)py * a.map.width + px : 0;
+// The planning step of one pass, for the wave's 64 rays at once (shared by the plan kernel — first pass — and the
+// composite kernel, which plans the NEXT pass for the rays it has just advanced: one launch and one round trip of the
+// ray records less per pass).  `r` holds the ray's (t, T, C); `goes` = it hit the box and is above the ERT threshold.
+__device__ __forceinline__ void c5_plan_rows(const K1Args& a, bool mine, int64_t pix, C5Ray r, bool goes, float t1,
+                                             C5Ray* __restrict__ rays, uint2* __restrict__ rowOwner,
+                                             uint32_t* __restrict__ counter, uint32_t chunk) {
     uint32_t cnt = 0;
-    if (mine) {
-        float ro[3], rd[3], t0, t1;
-        const bool hit = setup_ray(a, px, py, ro, rd, t0, t1);
-        if (first) r.t = t0; else r = rays[pix];
-        if (hit && r.T > a.ert) {
-            float t = r.t;
-            for (; cnt < chunk && t < t1; ++cnt) t += a.stepSize;           // the march's own running sum
-        }
+    if (mine && goes) {
+        float t = r.t;
+        for (; cnt < chunk && t < t1; ++cnt) t += a.stepSize;               // the march's own running sum
     }
     // the wave's row range inside the pass's batch: one atomic per wave
     uint32_t total = cnt;
@@ -611,6 +605,23 @@ __global__ __launch_bounds__(256) void c5_plan_kernel(const K1Args a, C5Ray* __r
     C5Rows rows(base);
     for (uint32_t k = 0; rows.step(cnt > k); ++k)
         if (cnt > k) rowOwner[rows.row] = make_uint2((uint32_t)pix, k);       // stores only: nothing waits on them
+}
+
+__global__ __launch_bounds__(256) void c5_plan_kernel(const K1Args a, C5Ray* __restrict__ rays, uint2* __restrict__ rowOwner,
+                                                      uint32_t* __restrict__ counter, uint32_t chunk) {
+    uint32_t px, py;
+    int64_t oidx;
+    const bool mine = map_pixel(a.map, px, py, oidx) == 1;
+    C5Ray r = { 0.0f, 1.0f, a.bg[0], a.bg[1], a.bg[2], 0u, 0u, 0u };
+    const int64_t pix = mine ? (int64_t)py * a.map.width + px : 0;
+    float t1 = 0.0f;
+    bool goes = false;
+    if (mine) {
+        float ro[3], rd[3], t0;
+        goes = setup_ray(a, px, py, ro, rd, t0, t1) && r.T > a.ert;
+        r.t = t0;
+    }
+    c5_plan_rows(a, mine, pix, r, goes, t1, rays, rowOwner, counter, chunk);
 }
 
 // One thread per ROW of the pass's batch (not per ray): the emission of a pass is ~10^6 independent samples, each
@@ -664,18 +675,22 @@ __global__ __launch_bounds__(256) void c5_emit_kernel(const K1Args a, const Emit
 template <bool STRICT, bool SHADE>
 __global__ __launch_bounds__(256) void c5_composite_kernel(const K1Args a, C5Ray* __restrict__ rays,
                                                            const int16_t* __restrict__ classes,
-                                                           const float* __restrict__ mix, const uint32_t* __restrict__ seg) {
+                                                           const float* __restrict__ mix, const uint32_t* __restrict__ seg,
+                                                           uint2* __restrict__ rowOwner, uint32_t* __restrict__ nextCounter,
+                                                           uint32_t chunk) {
     uint32_t px, py;
     int64_t oidx;
     const int kind = map_pixel(a.map, px, py, oidx);
     RayState r = { a.bg[0], a.bg[1], a.bg[2], 1.0f, 0u, 0u };
     const int64_t pix = kind == 1 ? (int64_t)py * a.map.width + px : 0;
     C5Ray st = { 0.0f, 1.0f, 0.0f, 0.0f, 0.0f, 0u, 0u, 0u };
-    float rd[3] = { 0.0f, 0.0f, 1.0f };
+    float rd[3] = { 0.0f, 0.0f, 1.0f }, t1 = 0.0f;
+    bool hit = false;
     if (kind == 1) {
         st = rays[pix];
         r.C0 = st.C0; r.C1 = st.C1; r.C2 = st.C2; r.T = st.T;
-        if (SHADE && st.cnt != 0) { float ro[3], t0, t1; setup_ray(a, px, py, ro, rd, t0, t1); }
+        float ro[3], t0;
+        if (nextCounter != nullptr || (SHADE && st.cnt != 0)) hit = setup_ray(a, px, py, ro, rd, t0, t1);
     }
     struct Rec { float v, g[3]; Labels lb; };
     auto fetch = [&](uint32_t row, bool takes, Rec& c) {
@@ -709,10 +724,9 @@ __global__ __launch_bounds__(256) void c5_composite_kernel(const K1Args a, C5Ray
         }
         cur = nxt;
     }
-    if (kind == 1 && st.cnt != 0) {
-        st.t = t; st.T = r.T; st.C0 = r.C0; st.C1 = r.C1; st.C2 = r.C2;
-        rays[pix] = st;
-    }
+    st.t = t; st.T = r.T; st.C0 = r.C0; st.C1 = r.C1; st.C2 = r.C2;
+    // the next pass's plan for these rays (nullptr after the last pass: nothing is parked)
+    if (nextCounter != nullptr) c5_plan_rows(a, kind == 1, pix, st, hit && r.T > a.ert, t1, rays, rowOwner, nextCounter, chunk);
     finish(a, kind, oidx, r);      // the frame so far (complete after the last pass); live-sample counters
 }
 
@@ -1085,9 +1099,11 @@ static int c5_launch_plan(const K1Args& a, const EmitArgs& e, uint32_t layout, b
     // the C5 passes read LINEAR / BRICK / VG / QUAD grids; QUAD carries no gradients
     if (layout > MRIRT_LAYOUT_QUAD || (layout == MRIRT_LAYOUT_QUAD && shade)) return MRIRT_ERR_LAYOUT;
     uint32_t* counter = sc.counters + pass;
-    hipLaunchKernelGGL(c5_plan_kernel, dim3(a.map.chunk * kXcds), dim3(a.map.blockPx == 8 ? 64 : 256), 0, s,
-                       a, sc.rays, sc.rowOwner, counter, chunk, pass == 0 ? 1u : 0u);
-    MRIRT_HIP(hipGetLastError());
+    if (pass == 0) {                                                  // later passes are planned by the composite kernel
+        hipLaunchKernelGGL(c5_plan_kernel, dim3(a.map.chunk * kXcds), dim3(a.map.blockPx == 8 ? 64 : 256), 0, s,
+                           a, sc.rays, sc.rowOwner, counter, chunk);
+        MRIRT_HIP(hipGetLastError());
+    }
     const int64_t blocksWanted = (sc.cap + 255) / 256;
     const dim3 grid((uint32_t)(blocksWanted < 4096 ? blocksWanted : 4096)), block(256);
 #define MRIRT_C5E(L, SH) hipLaunchKernelGGL((c5_emit_kernel<STRICT, L, SH>), grid, block, 0, s, a, e, sc.rays, sc.rowOwner, counter)
@@ -1103,10 +1119,10 @@ static int c5_launch_plan(const K1Args& a, const EmitArgs& e, uint32_t layout, b
 }
 
 template <bool STRICT>
-static int c5_launch_composite(const K1Args& a, bool shade, const C5Scratch& sc, hipStream_t s) {
+static int c5_launch_composite(const K1Args& a, bool shade, const C5Scratch& sc, uint32_t* nextCounter, uint32_t chunk, hipStream_t s) {
     const dim3 grid(a.map.chunk * kXcds), block(a.map.blockPx == 8 ? 64 : 256);     // the plan kernel's pixel -> lane map
-    if (shade) hipLaunchKernelGGL((c5_composite_kernel<STRICT, true>), grid, block, 0, s, a, sc.rays, sc.classes, sc.mix, sc.seg);
-    else       hipLaunchKernelGGL((c5_composite_kernel<STRICT, false>), grid, block, 0, s, a, sc.rays, sc.classes, sc.mix, sc.seg);
+    if (shade) hipLaunchKernelGGL((c5_composite_kernel<STRICT, true>), grid, block, 0, s, a, sc.rays, sc.classes, sc.mix, sc.seg, sc.rowOwner, nextCounter, chunk);
+    else       hipLaunchKernelGGL((c5_composite_kernel<STRICT, false>), grid, block, 0, s, a, sc.rays, sc.classes, sc.mix, sc.seg, sc.rowOwner, nextCounter, chunk);
     MRIRT_HIP(hipGetLastError());
     return MRIRT_OK;
 }
@@ -1156,7 +1172,9 @@ extern "C" int mrirt_render_brats_inr(const MrirtBratsParams* p, const MrirtRend
         if (rc != MRIRT_OK) return rc;
         rc = inr_forward_dev_n(net, sc.coords, sc.feats, sc.cap, sc.counters + c, sc.classes, s);
         if (rc != MRIRT_OK) return rc;
-        rc = strict ? c5_launch_composite<true>(a, cfg.shade, sc, s) : c5_launch_composite<false>(a, cfg.shade, sc, s);
+        uint32_t* next = c + 1 < (uint32_t)passes ? sc.counters + c + 1 : nullptr;
+        rc = strict ? c5_launch_composite<true>(a, cfg.shade, sc, next, chunk_steps, s)
+                    : c5_launch_composite<false>(a, cfg.shade, sc, next, chunk_steps, s);
         if (rc != MRIRT_OK) return rc;
     }
     if (stats_dev != nullptr) {                                               // stats_dev[2] += MLP queries of the frame
