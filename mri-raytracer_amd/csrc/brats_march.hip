@@ -602,9 +602,11 @@ __device__ __forceinline__ void c5_plan_rows(const K1Args& a, bool mine, int64_t
         rays[pix] = r;
     }
     // rows in (step, lane) order: the wave's rays that take step k are neighbours in the batch, as they are in the volume
+    // each row records its pixel and its t (the running sum again: the emission needs neither the ray record nor k)
     C5Rows rows(base);
-    for (uint32_t k = 0; rows.step(cnt > k); ++k)
-        if (cnt > k) rowOwner[rows.row] = make_uint2((uint32_t)pix, k);       // stores only: nothing waits on them
+    float t = r.t;
+    for (uint32_t k = 0; rows.step(cnt > k); ++k, t += a.stepSize)
+        if (cnt > k) rowOwner[rows.row] = make_uint2((uint32_t)pix, __float_as_uint(t));   // stores only: nothing waits on them
 }
 
 __global__ __launch_bounds__(256) void c5_plan_kernel(const K1Args a, C5Ray* __restrict__ rays, uint2* __restrict__ rowOwner,
@@ -628,11 +630,10 @@ __global__ __launch_bounds__(256) void c5_plan_kernel(const K1Args a, C5Ray* __r
 // of them eight gathers and a few hundred flops, and a per-ray loop serialises a ray's 32 behind one another's
 // memory latency with one wave per SIMD slot to hide it (measured: 0.18 ms per pass at 512^2, 1.6 ms of a
 // 10.5 ms frame).  The rows of a wave are the same step of neighbouring rays (C5Rows), so the gathers stay as
-// coherent as the march's own and the stores are contiguous; t is rebuilt by the march's own running sum from
-// the ray's parked t (k <= chunk adds).
+// coherent as the march's own and the stores are contiguous; the plan recorded each row's pixel and t.
 template <bool STRICT, int LAYOUT, bool SHADE>
-__global__ __launch_bounds__(256) void c5_emit_kernel(const K1Args a, const EmitArgs e, const C5Ray* __restrict__ rays,
-                                                      const uint2* __restrict__ rowOwner, const uint32_t* __restrict__ counter) {
+__global__ __launch_bounds__(256) void c5_emit_kernel(const K1Args a, const EmitArgs e, const uint2* __restrict__ rowOwner,
+                                                      const uint32_t* __restrict__ counter) {
     using Mm = M<STRICT>;
     const uint32_t n = *counter;
     for (uint32_t row = blockIdx.x * blockDim.x + threadIdx.x; row < n; row += gridDim.x * blockDim.x) {
@@ -640,8 +641,7 @@ __global__ __launch_bounds__(256) void c5_emit_kernel(const K1Args a, const Emit
         const uint32_t py = own.x / a.map.width, px = own.x - py * a.map.width;
         float ro[3], rd[3], t0, t1;
         setup_ray(a, px, py, ro, rd, t0, t1);
-        float t = rays[own.x].t;
-        for (uint32_t k = 0; k < own.y; ++k) t += a.stepSize;
+        const float t = __uint_as_float(own.y);
         Cell s;
         locate<STRICT>(a, ro, rd, t, s);
         float sv[4];
@@ -1106,7 +1106,7 @@ static int c5_launch_plan(const K1Args& a, const EmitArgs& e, uint32_t layout, b
     }
     const int64_t blocksWanted = (sc.cap + 255) / 256;
     const dim3 grid((uint32_t)(blocksWanted < 4096 ? blocksWanted : 4096)), block(256);
-#define MRIRT_C5E(L, SH) hipLaunchKernelGGL((c5_emit_kernel<STRICT, L, SH>), grid, block, 0, s, a, e, sc.rays, sc.rowOwner, counter)
+#define MRIRT_C5E(L, SH) hipLaunchKernelGGL((c5_emit_kernel<STRICT, L, SH>), grid, block, 0, s, a, e, sc.rowOwner, counter)
     switch (layout) {
         case MRIRT_LAYOUT_LINEAR: if (shade) MRIRT_C5E(0, true); else MRIRT_C5E(0, false); break;
         case MRIRT_LAYOUT_BRICK:  if (shade) MRIRT_C5E(1, true); else MRIRT_C5E(1, false); break;
