@@ -173,6 +173,13 @@ def test_c5_chunked_is_bit_identical_to_one_pass(setup, kind):
         assert a["live_samples"] == ash["live_samples"] and a["shaded_samples"] == ash["shaded_samples"]
     br = [mrirt.upload_grid(v, dims, "brick") for v in s["vols"]]
     assert torch.equal(inr.render_brats_inr(p, br, net, s["zmu"], s["zsg"], labels=gl, chunk_steps=7), ref)
+    # an image whose sides are not multiples of the 8 x 8 packet (lanes outside the image take part in the wave's
+    # row numbering with zero samples)
+    p2 = dict(p, imageSize=(37, 29))
+    ref2 = inr.render_brats_inr(p2, grids, net, s["zmu"], s["zsg"], labels=gl, one_pass=True)
+    assert ref2.shape[:2] == (29, 37)
+    for chunk in (2, 32):
+        assert torch.equal(inr.render_brats_inr(p2, grids, net, s["zmu"], s["zsg"], labels=gl, chunk_steps=chunk), ref2)
 
 
 def test_c5_as_named_siren_4x256_512x512_256_samples():
