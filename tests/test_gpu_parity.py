@@ -387,7 +387,8 @@ def test_shim_k2_marches_the_cell8_copy():
     assert np.array_equal(frames[0], frames[1]) and frames[0][..., 0].max() > 0.05
 
 
-def test_c4_full_size_tiles_over_eight_ranks(env):
+@pytest.mark.parametrize("layout", ["vg", "vga"])          # vga (16 x 16-pixel workgroups) is what bench.py --gpus N marches
+def test_c4_full_size_tiles_over_eight_ranks(env, layout):
     """BASELINE config 4 at full size on one GPU: 512^3, 2048 x 2048, 512 steps, shaded, 64 x 64 tiles dealt to 8
     'ranks'.  Each rank's compact tile buffer, gathered and de-tiled (the HIP de-tiling kernel), must be the
     whole-frame render bit for bit, and the ranks' live-sample counts must add up to the whole frame's."""
@@ -395,9 +396,9 @@ def test_c4_full_size_tiles_over_eight_ranks(env):
     from mrirt import tiles
     n, image, steps, world, tile = 512, 2048, 512, 8, 64
     vol = synth.synth_volume(n)
-    g = mrirt.upload_grid(vol, (n, n, n), "vg")
+    g = mrirt.upload_grid(vol, (n, n, n), layout)
     p = synth.brats_scene(n, image, steps, channels=1, intensity_alpha=16.0)
-    ext = dict(synth.SHADE_EXT, layout="vg")
+    ext = dict(synth.SHADE_EXT, layout=layout)
     whole, sw = mrirt.render_brats(p, [g], ext=ext, stats=True)
     max_local = tiles.local_tile_count(image, image, tile, 0, world)
     gathered = torch.zeros((world, max_local, tile, tile, 4), device="cuda")
