@@ -255,3 +255,51 @@ def test_k1_frame_agrees_with_an_independent_torch_march():
     assert np.quantile(d, 0.999) <= 1e-4, np.quantile(d, 0.999)
     assert d.max() <= 0.011
     assert abs(live - int(aux["nsteps"].sum())) <= 0.002 * live
+
+
+def test_k2_frame_agrees_with_an_independent_torch_march():
+    """volume_cs (scripts/volumeRendering/volume_render.slang:104-148) restated a second time, differently: fp64,
+    sample positions as near + i * step (no running sum), the u8 trilinear fetch through torch's grid_sample
+    (align_corners=True, i.e. texel = sat(0.5 (x + 1)) * (dim - 1) as :46-49).  Bounds how wrong oracle_np.volume_cs
+    could be; pixels whose ray grazes a cube face or stops within rounding of 0.995 may take one sample more or
+    fewer (one sample weighs at most 4 / steps)."""
+    import torch
+    import torch.nn.functional as F
+    from mrirt import synth
+    n, image, steps = 40, 64, 96
+    u8 = synth.synth_u8_volume(n)
+    p = synth.volume_scene(n, image, steps, near=1.5, far=4.5)
+    ref, aux = onp.volume_cs(p, u8, mode="u8", return_aux=True)
+    assert np.array_equal(ref, oracle_c.volume_cs(p, onp.pack_u8_volume(u8)))
+    W, H = int(p["imageSize"][0]), int(p["imageSize"][1])
+    f64 = torch.float64
+    eye, U, V, Wv = (torch.tensor(np.asarray(p[k], np.float64)) for k in ("eye", "U", "V", "W"))
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=f64), torch.arange(W, dtype=f64), indexing="ij")
+    ndcx = (xs + 0.5) / W * 2 - 1
+    ndcy = 1 - (ys + 0.5) / H * 2
+    th = np.tan(0.5 * float(p["fovY"]))
+    view = torch.stack([ndcx * (W / max(1, H)) * th, ndcy * th, torch.ones_like(ndcx)], -1)      # :109-113
+
+    def plane(d):
+        v = view * d
+        return eye + v[..., 0:1] * U + v[..., 1:2] * V + v[..., 2:3] * Wv
+
+    near, far = float(p["nearPlane"]), float(p["farPlane"])
+    a, b = plane(max(0.0, near)), plane(max(max(0.0, near), far))
+    step = (b - a) / steps
+    vol = torch.from_numpy(u8.reshape(n, n, n).astype(np.float64) / 255.0)[None, None]
+    accum = torch.zeros(H, W, dtype=f64)
+    alive = torch.ones(H, W, dtype=torch.bool)
+    fetched = 0
+    for i in range(steps):
+        pos = a + step * i
+        inside = ((pos < 1) & (pos > -1)).all(-1)
+        do = alive & inside & (accum < 1)
+        s = F.grid_sample(vol, pos.clamp(-1, 1)[None, None], mode="bilinear", padding_mode="border", align_corners=True)[0, 0, 0]
+        accum = torch.where(do, accum + (1 - accum) * s * (4.0 / steps), accum)
+        fetched += int(do.sum())
+        alive = alive & ~(accum > 0.995)
+    d = np.abs(accum.numpy() - ref[..., 0])
+    assert np.quantile(d, 0.999) <= 1e-4, np.quantile(d, 0.999)
+    assert d.max() <= 4.0 / steps + 1e-4
+    assert abs(fetched - aux["live_samples"]) <= 0.002 * fetched and fetched > 10000
