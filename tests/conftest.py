@@ -22,12 +22,13 @@ def golden_dir():
 @pytest.fixture(scope="session", autouse=True)
 def _fresh_hip_library():
     """On a GPU box, make sure the in-tree libmrirt.so matches the sources before any test loads it (a no-op
-    when it is up to date; the snapshot normally carries the library __graft_entry__.build() produced).  The
-    product itself never builds or falls back implicitly — this is test hygiene only."""
+    when it is up to date; the snapshot normally carries the library __graft_entry__.build() produced); on a box
+    without a GPU, build it when it is missing altogether (a fresh clone: the ABI tests dlopen it).  The product
+    itself never builds or falls back implicitly — this is test hygiene only."""
     try:
         import torch
-        if torch.cuda.is_available():
-            import mrirt
+        import mrirt
+        if torch.cuda.is_available() or not mrirt._lib.SO_PATH.exists():
             mrirt._lib.build()
     except Exception as e:                      # no hipcc on the box: the tests will say what is missing
         print(f"[conftest] libmrirt.so not rebuilt: {e}")
