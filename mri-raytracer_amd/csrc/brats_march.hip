@@ -779,13 +779,15 @@ static int prepare(const MrirtBratsParams* p, const MrirtRenderExt* ext, const v
         if (sqrt(diag2) / (double)h > (double)kMaxStepsPerRay) return MRIRT_ERR_ARG;
     }
     fill_camera(a.cam, p->eye, p->U, p->V, p->W, p->fovY, p->imageSize[0], p->imageSize[1], ext, false);
-    // XCD-interleaved bands of 16 px by default (variant bit 3: contiguous run per XCD; bits 4-5: 8/32/64 px)
-    const uint32_t bandSel = (variant >> 4) & 3u;
-    const uint32_t bandPx = (variant & 8u) ? 0u : (bandSel == 0 ? 16u : bandSel == 1 ? 8u : bandSel == 2 ? 32u : 64u);
     // Workgroup = one 8 x 8 packet (64 threads: a finished packet's wave slot refills at once) — except on VGA grids, where
     // a 16 x 16 block of four packets measured 3.7 % faster (1.145 -> 1.10 ms at C3: the four waves' lines meet in one L1).
     // Variant bit 1 flips the choice; the LDS-staged kernel (bit 6) is written for one packet per workgroup.
     const bool bigBlocks = ((variant & 2u) != 0u) != (layout == MRIRT_LAYOUT_VGA && (variant & 64u) == 0u);
+    // XCD-interleaved bands one workgroup row high by default (8-px bands for 8 x 8 workgroups: config 2 0.606 -> 0.580 ms,
+    // K1 at 512^3 level; variant bit 3: contiguous run per XCD; bits 4-5: 16 / 8 / 32 / 64 px)
+    const uint32_t bandSel = (variant >> 4) & 3u;
+    const uint32_t bandAsked = bandSel == 0 ? (bigBlocks ? 16u : 8u) : bandSel == 1 ? 16u : bandSel == 2 ? 32u : 64u;
+    const uint32_t bandPx = (variant & 8u) ? 0u : bandAsked;
     int rc = fill_pixel_map(a.map, p->imageSize[0], p->imageSize[1], pitch_px, ext,
                             bigBlocks ? 16u : 8u, (variant & 1u) ? 0u : 1u, bandPx);
     if (rc != MRIRT_OK) return rc;
@@ -914,7 +916,7 @@ using namespace mrirt;
 
 // kernelVariant toggles (experiments; 0 = library default):
 //   bit 0: row-major instead of Morton lane order      bit 1: flip 64- / 256-thread workgroups (256 is the default on VGA)
-//   bit 2: no software pipelining                      bits 3-5: XCD band height (prepare())
+//   bit 2: no software pipelining                      bits 3-5: XCD band height (prepare(); bits 4-5 = 1: 16 px)
 //   bit 6: the LDS-staged kernel of brats_slab.hip     bit 7: ... counts its LDS-served samples in stats[1]
 //   bit 8: skipping one step at a time (no leaps); in the slab kernel: count ring misses
 extern "C" int mrirt_render_brats_ex(const MrirtBratsParams* p, const MrirtRenderExt* ext,
