@@ -81,11 +81,10 @@ __global__ __launch_bounds__(256) void brats_march_kernel(const K1Args a) {
 // ---------------------------------------------------------------------------------------
 // LABELS == false: neither overlay is shown, so the stage carries no label words and pIdx dies after
 // locate() — about ten VGPRs less across the two stages, which is what lets the kernel fit 4 waves/SIMD.
-// SKIP: exact empty-space skipping.  A sample whose 8^3 macro cell is flagged in a.skipMask (per-launch
-// bit mask: no enabled modality can lift the transfer function above 0 there and no shown label grid has
-// a label there — skip_mask_kernel) still counts as a march step, but fetches and composites nothing:
-// the frame and the counters are the same bits as without skipping.  The flag of the lane's current
-// macro cell is cached; the mask is re-read only when the sample leaves the cell.
+// SKIP: exact empty-space skipping (march_skip below).  A sample whose 8^3 macro cell is flagged (per launch:
+// no enabled modality can lift the transfer function above 0 there and no shown label grid has a label there —
+// skip_mask_kernel; a.skipDist holds the flags as an empty-radius map, byte != 0 = flagged) still counts as a
+// march step, but composites nothing: the frame and the counters are the same bits as without skipping.
 // Second level (a.leap): the map byte r of a sample's macro cell says that every macro cell within Chebyshev distance
 // r - 1 is flagged too, so the ray may move 8 (r - 1) voxels along every axis and still be in flagged cells.  When every
 // live ray of the packet is in a flagged cell, the packet takes the smallest of its lanes' budgets at
@@ -552,10 +551,12 @@ __global__ __launch_bounds__(256) void emit_samples_kernel(const K1Args a, const
 //   plan:      every ray still alive (t < t1 and T > ert after the previous pass) counts its next <= chunk steps and
 //              its wave takes a row range of the pass's batch (one atomic per wave); the batch size stays in device
 //              memory (no host round trip);
-//   emit:      one thread per row of the batch writes that sample's MLP inputs;
+//   emit:      one thread per row of the batch writes that sample's MLP inputs and what the compositor needs of it
+//              besides the class (weighted intensity, gradient when shading, seg label);
 //   classify:  mrirt's MFMA forward over that batch (inr_mlp.hip, point count read from the device word);
-//   composite: the same rays march those steps with the class stream, exactly as brats_main does (ERT tested
-//              before every step), and park their state (t, T, C) for the next pass.
+//   composite: the same rays composite those steps from the per-row records, exactly as brats_main does (ERT tested
+//              before every step), park their state (t, T, C) — and plan the NEXT pass (the plan kernel itself only
+//              runs for the first one).
 // A ray that terminates inside a pass has at most chunk - 1 samples classified in vain; a ray that is dead
 // costs nothing in later passes.  The frame is the same bits as the one-pass form (the MLP is batch-position
 // invariant), which tests/test_gpu_inr_render.py holds it to.

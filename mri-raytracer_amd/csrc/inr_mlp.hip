@@ -590,14 +590,15 @@ __global__ __launch_bounds__(512) void inr_forward_kernel(const InrArgs a) {
 // through LDS for every 256 points, and the point count per CU is capped by the register file that holds the
 // activations).  Here the roles are swapped: the WEIGHTS live in the register file for the whole launch — a
 // CU's four SIMDs hold 4 x 128 KiB of registers, the network is 416 KiB — and the ACTIVATIONS travel through
-// LDS.  One wave per SIMD (512 registers); wave w owns out tiles 2w and 2w+1 of every layer (416 registers of
-// A fragments: 16 layer-0, 3 x 128 hidden, 16 head); a round is G = 4 groups of 32 points; per layer a wave reads
+// LDS.  One wave per SIMD (512 registers); wave w owns out tiles 2w and 2w+1 of the three hidden layers (384 registers
+// of A fragments: layers 1 and 2 in the AGPR half through "a"-constrained MFMAs, layer 3 in VGPRs, its last four
+// fragments and the small layer-0 / head fragments in LDS); a round is G = 3 groups of 32 points; per layer a wave reads
 // a group's sixteen 1-KiB B fragments from LDS (what all four waves wrote in the previous phase), runs its
 // 2 x 16 MFMAs, and writes its two out tiles back as the next layer's B fragments 4w .. 4w+3 (the accumulator
-// layout IS the B layout, as above: two ds_write_b128 per tile).  The head is split over k: wave w multiplies
-// its own 64 output features of the last hidden layer (still in registers) with its slice of the head and
-// leaves 4 partial logits per point in LDS; wave g sums the four partials of group g in a fixed order.  No weight
-// traffic at all after the prologue, one workgroup barrier per layer phase (128 MFMAs per wave apart).
+// layout IS the B layout, as above: two ds_write_b128 per tile).  The head is one out tile: wave g (g < G) runs it
+// for group g, one round late, interleaved with the next round's layer 0 (which is VALU-bound: two MFMAs and sixteen
+// sines per tile pass, while the head is sixteen MFMAs and no activation).  No weight traffic at all after the
+// prologue, one workgroup barrier per phase (four per round).
 // Tried and measured no faster (round 2, s_memtime stamps + wall): a second schedule that chains the passes across phase
 // and round boundaries with two write-only barriers per phase (post-op always under the next pass, ring running on
 // into the next layer) — 20.0 k cycles per round against 18.1 k here; a micro-benchmark of the pass (tools/micro/
@@ -605,9 +606,8 @@ __global__ __launch_bounds__(512) void inr_forward_kernel(const InrArgs a) {
 // previous tile's activation add ~160 on top instead of hiding (709) — with one wave per SIMD the VALU work of the gaps
 // that carry two sines overflows the 24 issue cycles an MFMA leaves.
 // Same packed image, same arithmetic per point (accumulator starts at the bias, k steps in ascending order):
-// bit-identical logits to the streaming kernel for the hidden layers' inputs; the head sums four k-quarter
-// partials in fp32 instead of one running chain, so logits may differ from it in the last bit (the tests hold both
-// kernels to the same fp32 / fp64 references, and each is batch-position invariant by construction).
+// bit-identical logits to the streaming kernel (tools/ws_check.py; the tests hold both kernels to the same fp32 /
+// fp64 references, and each is batch-position invariant by construction).
 // =====================================================================================================
 constexpr int kWsGroups = 3;
 // Diagnostic build (-DMRIRT_WS_STAMPS): s_memtime at the phase boundaries of one steady-state round of every
@@ -645,8 +645,8 @@ __global__ __launch_bounds__(256, 1) void inr_ws_kernel(const InrArgs a) {
 #define MRIRT_WS_RD 4
 #endif
     constexpr int G = kWsGroups, NH = 3, KS = 16, RD = MRIRT_WS_RD;      // RD: B fragments in flight ahead of their MFMA
-    constexpr int kActQ = G * 2 * KS * 64;               // uint4: [group][parity][k step][lane]   128 KiB
-    constexpr int kInQ = G * 2 * 64;                     // layer-0 B fragments (k steps 0, 1)       8 KiB
+    constexpr int kActQ = G * 2 * KS * 64;               // uint4: [group][parity][k step][lane]    96 KiB
+    constexpr int kInQ = G * 2 * 64;                     // layer-0 B fragments (k steps 0, 1)       6 KiB
     constexpr int kPartQ = 0;                            // (head partials of an earlier k-split head: gone)
     constexpr int kBiasQ = (4 * 256 + 32) / 4;           // padded biases                          4.1 KiB
     constexpr int kW0Q = 16 * 64, kWoQ = 16 * 64;        // layer-0 and head A fragments (all waves')   16 + 16 KiB

@@ -226,7 +226,7 @@ _last_skip_mask: Optional[torch.Tensor] = None
 
 def _bind_skip(P, intensities, labels, preds, dev):
     """MrirtSkip for one call: the macro summaries of the bound Grid objects + a mask scratch of this call's own
-    (a few KB from the caching allocator, on the launch stream: skip_mask_kernel rewrites it on every launch, so a
+    (a few hundred KB from the caching allocator, on the launch stream: the pre-pass rewrites it on every launch, so a
     scratch shared between calls would be overwritten under a march still reading it on another stream)."""
     S = _lib.Skip()
     keep = []
@@ -266,7 +266,8 @@ def render_brats(params: Mapping[str, Any], intensities: Sequence[Optional[Union
 
     ``skip=True`` turns on exact empty-space skipping (same bits, same counters; needs the bound grids to be
     ``Grid`` objects carrying their macro-cell summaries, i.e. made by ``upload_grid``): samples in 8^3 macro
-    cells that cannot contribute under this call's window, weights and overlays fetch nothing.
+    cells that cannot contribute under this call's window, weights and overlays composite nothing, and the packet
+    crosses wide empty regions in leaps sized by an empty-radius map of those cells.
     """
     dev = _require_gpu()
     # every temporary of this call (uploads of host arrays, the output, the counters, the skip mask) is made on
