@@ -158,9 +158,10 @@ class ComputeKernel:
         raw = [vars[f"gIntensity{m}"] for m in range(4)] + [vars["gLabels"], vars["gPreds"]]
         if not all(isinstance(b, Buffer) for b in raw):
             layout = "linear"
-        # "auto": float4 voxels in 2x2x2 bricks — value+gradient when shading, xy-quads otherwise;
-        # label grids in 4x4x2 bricks.  Derived copies are cached on the Buffer until it is rewritten.
-        vlay = ("vg" if int(e.get("shadeMode", 0)) else "quad") if layout == "auto" else layout
+        # "auto": float4 voxels — value+gradient in axis-flat bricks (three copies, "vga") when shading, xy-quads in
+        # 2x2x2 bricks otherwise; label grids in 4x4x2 bricks.  Derived copies are cached on the Buffer until it is
+        # rewritten.
+        vlay = ("vga" if int(e.get("shadeMode", 0)) else "quad") if layout == "auto" else layout
         llay = "linear" if layout == "linear" else "brick"
         # dummy 1-element buffers stand in for disabled inputs (brats_viewer.py:247-248,437-438)
         en = [int(v) != 0 for v in p["volEnabled"]] + [int(p["showSeg"]) != 0, int(p["showPred"]) != 0]
@@ -168,7 +169,7 @@ class ComputeKernel:
         bound = [self._buf(b, dims, lay) if on else None for b, on, lay in zip(raw, en, lays)]
         e["layout"], e["labelLayout"] = vlay, llay
         # exact empty-space skipping rides on the macro-cell summaries upload_grid attached to the cached grids
-        skip = (self.device.skip_empty and vlay in ("vg", "quad")
+        skip = (self.device.skip_empty and vlay in ("vg", "vga", "quad")
                 and all(b is None or (isinstance(b, _r.Grid) and b.macro is not None) for b in bound))
         _r.render_brats(p, bound[:4], bound[4], bound[5], out=tex.tensor, ext=e, skip=skip)
 
