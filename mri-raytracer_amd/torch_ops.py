@@ -87,6 +87,8 @@ def _grid_need(dims: Sequence[int], layout: int) -> int:
         return dims[0] * dims[1] * dims[2]
     if layout == _lib.LAYOUT_BRICK:
         return int(l.mrirt_brick_elems(d))
+    if layout == _lib.LAYOUT_VGA:                    # three axis-flat copies of the float4 voxels
+        return 4 * int(l.mrirt_vga_elems(d))
     return 4 * int(l.mrirt_vec4_elems(d))
 
 

@@ -17,7 +17,7 @@ def test_render_brats_op_equals_api_and_oracle():
     p = synth.brats_scene(n, image, 64, channels=1, intensity_alpha=8.0)
     p["showSeg"] = 1
     ref = oracle_c.brats_main(p, [vol], lab, None, dict(synth.SHADE_EXT))
-    for layout in ("linear", "vg"):
+    for layout in ("linear", "vg", "vga"):
         ext = dict(synth.SHADE_EXT, layout=layout, labelLayout="linear")
         g = mrirt.upload_grid(vol, (n, n, n), layout)
         labels = torch.from_numpy(lab.astype(np.int32)).cuda()
