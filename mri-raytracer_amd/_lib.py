@@ -135,6 +135,40 @@ def build(force: bool = False, verbose: bool = False) -> pathlib.Path:
     return SO_PATH
 
 
+# --- the C++ PyTorch extension (csrc/torch_binding.cpp -> libmrirt_torch.so: torch.ops.mrirt_native.*) ------------
+TORCH_SO_PATH = PKG_DIR / "libmrirt_torch.so"
+
+
+def torch_binding_command() -> List[str]:
+    """Host-compiler command for the operator library: no device code, torch headers + libmrirt.so."""
+    import torch
+    from torch.utils import cpp_extension as ce
+    libdir = pathlib.Path(torch.__file__).resolve().parent / "lib"
+    inc = list(ce.include_paths()) + ["/opt/rocm/include", str(INCLUDE)]
+    return [os.environ.get("CXX", "g++"), "-O2", "-fPIC", "-shared", "-std=c++17", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+            f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", "-Wno-deprecated-declarations",
+            *[f"-I{i}" for i in inc], str(CSRC / "torch_binding.cpp"), "-o", str(TORCH_SO_PATH),
+            f"-L{libdir}", "-lc10", "-ltorch_cpu", "-ltorch", "-lc10_hip", "-ltorch_hip",
+            f"-L{PKG_DIR}", "-lmrirt", "-Wl,-rpath,$ORIGIN", f"-Wl,-rpath,{libdir}"]
+
+
+def build_torch_binding(force: bool = False, verbose: bool = False) -> pathlib.Path:
+    """Compile csrc/torch_binding.cpp against this interpreter's torch and the in-tree libmrirt.so."""
+    src = CSRC / "torch_binding.cpp"
+    stale = (not TORCH_SO_PATH.exists() or src.stat().st_mtime > TORCH_SO_PATH.stat().st_mtime
+             or (INCLUDE / "mrirt.h").stat().st_mtime > TORCH_SO_PATH.stat().st_mtime)
+    if force or stale:
+        build()                                   # links against libmrirt.so
+        cmd = torch_binding_command()
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if verbose or r.returncode != 0:
+            print(" ".join(cmd))
+            print(r.stdout + r.stderr)
+        if r.returncode != 0:
+            raise RuntimeError("building libmrirt_torch.so failed")
+    return TORCH_SO_PATH
+
+
 _LIB: Optional[C.CDLL] = None
 
 

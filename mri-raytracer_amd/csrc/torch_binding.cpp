@@ -1,0 +1,129 @@
+// torch.ops.mrirt_native.* — the C ABI of libmrirt.so (include/mrirt.h) registered as PyTorch operators from C++.
+//
+// Same contract as the Python registrations in mrirt/torch_ops.py (torch.ops.mrirt.*): device tensors in, a device
+// tensor out, launched on the current HIP stream, no synchronisation; parameter blocks travel as CPU uint8 tensors
+// holding the C structs byte for byte; every size check the C side cannot make (it only sees pointers) is made here.
+// No device code in this file: it is compiled by the host compiler against the torch headers and linked to
+// libmrirt.so, whose kernels do the work.  Replaces kernel.dispatch of inr/viewer/brats_viewer.py:431-442,
+// scripts/volumeRendering/app.py:350-358 and scripts/raymarch/app.py:212-223 for callers that want operators.
+#include <ATen/ATen.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
+#include <torch/library.h>
+
+#include <cstring>
+#include <optional>
+
+#include "mrirt.h"
+
+namespace {
+
+using at::Tensor;
+using OptTensor = std::optional<Tensor>;
+
+template <typename T>
+T unblob(const Tensor& t, const char* what) {
+    TORCH_CHECK_TYPE(t.device().is_cpu() && t.scalar_type() == at::kByte && t.numel() == (int64_t)sizeof(T),
+                     "expected a CPU uint8 tensor of ", sizeof(T), " bytes (", what, ")");
+    T v;
+    const Tensor c = t.contiguous();
+    std::memcpy(&v, c.data_ptr(), sizeof(T));
+    return v;
+}
+
+const void* dev_ptr(const OptTensor& t, at::ScalarType dt, const char* what) {
+    if (!t.has_value()) return nullptr;
+    TORCH_CHECK_TYPE(t->is_cuda() && t->scalar_type() == dt && t->is_contiguous(), what, ": expected a contiguous device tensor of the right dtype");
+    return t->data_ptr();
+}
+
+void* current_stream() { return (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream(); }
+
+void check(int rc, const char* where) {
+    TORCH_CHECK(rc == MRIRT_OK, where, ": ", mrirt_status_string(rc), " [status ", rc, "]");
+}
+
+std::vector<int64_t> out_shape(uint32_t width, uint32_t height, const MrirtRenderExt& e) {
+    if (e.tileSize > 0) {
+        const int64_t local = mrirt_tiles_for_rank(width, height, e.tileSize, e.tileRank, e.tileWorld);
+        return { local, (int64_t)e.tileSize, (int64_t)e.tileSize, 4 };
+    }
+    return { (int64_t)height, (int64_t)width, 4 };
+}
+
+int64_t grid_need(const uint32_t dims[3], uint32_t layout) {
+    switch (layout) {
+        case MRIRT_LAYOUT_LINEAR: return (int64_t)dims[0] * dims[1] * dims[2];
+        case MRIRT_LAYOUT_BRICK:  return mrirt_brick_elems(dims);
+        case MRIRT_LAYOUT_VGA:    return 4 * mrirt_vga_elems(dims);
+        default:                  return 4 * mrirt_vec4_elems(dims);
+    }
+}
+
+// brats_main (inr/viewer/brats_rt.slang:85-168) through mrirt_render_brats_ex
+Tensor render_brats(const Tensor& params, const Tensor& ext, const OptTensor& vol0, const OptTensor& vol1,
+                    const OptTensor& vol2, const OptTensor& vol3, const OptTensor& labels, const OptTensor& preds) {
+    const MrirtBratsParams P = unblob<MrirtBratsParams>(params, "MrirtBratsParams");
+    const MrirtRenderExt E = unblob<MrirtRenderExt>(ext, "MrirtRenderExt");
+    const OptTensor* vols[4] = { &vol0, &vol1, &vol2, &vol3 };
+    const char* names[4] = { "gIntensity0", "gIntensity1", "gIntensity2", "gIntensity3" };
+    const void* vp[4];
+    const int64_t need = grid_need(P.dims, E.layout), lneed = grid_need(P.dims, E.labelLayout);
+    std::optional<at::Device> dev;
+    for (int m = 0; m < 4; ++m) {
+        vp[m] = dev_ptr(*vols[m], at::kFloat, names[m]);
+        if (vols[m]->has_value() && !dev.has_value()) dev = (*vols[m])->device();
+        TORCH_CHECK_VALUE(P.volEnabled[m] == 0 || (vols[m]->has_value() && (*vols[m])->numel() >= need),
+                          names[m], " is enabled but holds fewer than ", need, " elements");
+    }
+    TORCH_CHECK_VALUE(dev.has_value(), "no intensity grid bound");
+    const void* lab = dev_ptr(labels, at::kInt, "gLabels");
+    const void* prd = dev_ptr(preds, at::kInt, "gPreds");
+    TORCH_CHECK_VALUE(P.showSeg == 0 || (labels.has_value() && labels->numel() >= lneed), "showSeg is set but gLabels is missing or too small");
+    TORCH_CHECK_VALUE(P.showPred == 0 || (preds.has_value() && preds->numel() >= lneed), "showPred is set but gPreds is missing or too small");
+    const auto dt = E.outFormat == MRIRT_OUT_RGBA16F ? at::kHalf : at::kFloat;
+    Tensor out = at::empty(out_shape(P.imageSize[0], P.imageSize[1], E), at::TensorOptions().dtype(dt).device(*dev));
+    check(mrirt_render_brats_ex(&P, &E, vp, lab, prd, out.data_ptr(), (int64_t)P.imageSize[0], nullptr, current_stream()),
+          "mrirt_render_brats_ex");
+    return out;
+}
+
+// volume_cs (scripts/volumeRendering/volume_render.slang:104-148) through mrirt_render_volume
+Tensor render_volume(const Tensor& params, const Tensor& ext, const Tensor& volume, int64_t mode) {
+    const MrirtVolumeParams P = unblob<MrirtVolumeParams>(params, "MrirtVolumeParams");
+    const MrirtRenderExt E = unblob<MrirtRenderExt>(ext, "MrirtRenderExt");
+    TORCH_CHECK_VALUE(mode >= 0 && mode <= 2, "mode must be 0 (u32x4), 1 (u8) or 2 (f32)");
+    const at::ScalarType want = mode == 0 ? at::kInt : mode == 1 ? at::kByte : at::kFloat;
+    const void* vol = dev_ptr(volume, want, "gVolumeU8");
+    const int64_t nvox = (int64_t)P.volDim[0] * P.volDim[1] * P.volDim[2];
+    TORCH_CHECK_VALUE(volume.numel() >= nvox, "gVolumeU8 holds fewer than ", nvox, " voxels");
+    const auto dt = E.outFormat == MRIRT_OUT_RGBA16F ? at::kHalf : at::kFloat;
+    Tensor out = at::empty(out_shape(P.imageSize[0], P.imageSize[1], E), at::TensorOptions().dtype(dt).device(volume.device()));
+    check(mrirt_render_volume(&P, &E, vol, (uint32_t)mode, out.data_ptr(), (int64_t)P.imageSize[0], nullptr, current_stream()),
+          "mrirt_render_volume");
+    return out;
+}
+
+// raymarch_cs (scripts/raymarch/raymarch.slang:60-99); `like` only names the device
+Tensor render_sdf(const Tensor& params, int64_t width, int64_t height, const Tensor& like) {
+    const MrirtSdfParams P = unblob<MrirtSdfParams>(params, "MrirtSdfParams");
+    TORCH_CHECK_TYPE(like.is_cuda(), "like: expected a device tensor");
+    Tensor out = at::empty({ height, width, 4 }, at::TensorOptions().dtype(at::kFloat).device(like.device()));
+    check(mrirt_render_sdf(&P, (uint32_t)width, (uint32_t)height, out.data_ptr<float>(), width, current_stream()), "mrirt_render_sdf");
+    return out;
+}
+
+}  // namespace
+
+TORCH_LIBRARY(mrirt_native, m) {
+    m.def("render_brats(Tensor params, Tensor ext, Tensor? vol0, Tensor? vol1, Tensor? vol2, Tensor? vol3, Tensor? labels, Tensor? preds) -> Tensor");
+    m.def("render_volume(Tensor params, Tensor ext, Tensor volume, int mode) -> Tensor");
+    m.def("render_sdf(Tensor params, int width, int height, Tensor like) -> Tensor");
+}
+
+// the parameter blocks are CPU tensors and the grids device tensors: no single dispatch key fits, so the
+// implementations are registered for every backend and check their arguments themselves
+TORCH_LIBRARY_IMPL(mrirt_native, CompositeExplicitAutograd, m) {
+    m.impl("render_brats", &render_brats);
+    m.impl("render_volume", &render_volume);
+    m.impl("render_sdf", &render_sdf);
+}

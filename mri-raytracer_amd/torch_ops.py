@@ -6,7 +6,8 @@ CPU ``uint8`` tensors holding the C structs of include/mrirt.h byte for byte (``
 & co. build them from the reference's ``gParams`` dicts), every size check the C side cannot make
 (it only sees pointers) is made here, and the launch itself is the same ``mrirt_*`` entry point the
 rest of the package calls.  There is no CPU implementation: the only other registration is the
-shape function ("fake" kernel) that ``torch.compile`` / meta tensors need.
+shape function ("fake" kernel) that ``torch.compile`` / meta tensors need.  The render operators also exist as a
+C++ extension (``load_native()`` -> ``torch.ops.mrirt_native.*``, csrc/torch_binding.cpp).
 
     blob = mrirt.torch_ops.pack_brats_params(gparams)
     ext  = mrirt.torch_ops.pack_render_ext({"layout": "vg", **mrirt.synth.SHADE_EXT})
@@ -22,6 +23,17 @@ import torch
 
 from . import _lib
 from .params import brats_params, render_ext, sdf_params, volume_params
+
+
+def load_native():
+    """``torch.ops.mrirt_native`` — the same render operators registered from C++ (csrc/torch_binding.cpp, a
+    PyTorch-ROCm C++ extension linked to libmrirt.so; schemas as ``torch.ops.mrirt.render_*`` below).  Raises if
+    libmrirt_torch.so has not been built (``__graft_entry__.build()``): like the HIP library, it has no fallback."""
+    if not _lib.TORCH_SO_PATH.exists():
+        raise ImportError(f"{_lib.TORCH_SO_PATH} is missing — build it with `python -c \"import __graft_entry__ as g; g.build()\"`.")
+    _lib.lib()                                    # libmrirt.so first: the operator library links against it
+    torch.ops.load_library(str(_lib.TORCH_SO_PATH))
+    return torch.ops.mrirt_native
 
 
 # --- parameter blocks <-> uint8 tensors ---------------------------------------------------------

@@ -69,3 +69,35 @@ def test_inr_forward_op_equals_api():
     api, _ = inr._forward(net, coords, feats, n, True, False)
     op = torch.ops.mrirt.inr_forward(net.weights, net.biases, inr.KIND_SIREN, 3, 7, 4, 64, 0, 4, 30.0, coords, feats, n)
     assert torch.equal(op, api)
+
+
+def test_native_cpp_operators_match_the_python_registered_ones():
+    """torch.ops.mrirt_native.* (csrc/torch_binding.cpp, the C++ extension) against torch.ops.mrirt.*: same frames."""
+    import torch
+    import mrirt
+    from mrirt import synth, torch_ops
+    ops = torch_ops.load_native()
+    n, image = 40, 96
+    vol, lab = synth.synth_volume(n), synth.synth_labels(n)
+    p = synth.brats_scene(n, image, 64, channels=1, intensity_alpha=8.0)
+    p["showSeg"] = 1
+    labels = torch.from_numpy(lab.astype(np.int32)).cuda()
+    for layout in ("linear", "vga", "quad"):
+        ext = dict(synth.SHADE_EXT if layout == "vga" else {}, layout=layout, labelLayout="linear")
+        g = mrirt.upload_grid(vol, (n, n, n), layout)
+        args = (torch_ops.pack_brats_params(p), torch_ops.pack_render_ext(ext), g.data, None, None, None, labels, None)
+        assert torch.equal(ops.render_brats(*args), torch.ops.mrirt.render_brats(*args))
+    half = torch_ops.pack_render_ext(dict(layout="quad", labelLayout="linear", outFormat="rgba16f", tileSize=32, tileRank=1, tileWorld=2))
+    a = ops.render_brats(torch_ops.pack_brats_params(p), half, g.data, None, None, None, labels, None)
+    b = torch.ops.mrirt.render_brats(torch_ops.pack_brats_params(p), half, g.data, None, None, None, labels, None)
+    assert a.dtype == torch.float16 and a.shape == b.shape and torch.equal(a, b)
+    with pytest.raises(ValueError):
+        ops.render_brats(torch_ops.pack_brats_params(p), torch_ops.pack_render_ext(ext), g.data[:100], None, None, None, labels, None)
+    pv = synth.volume_scene(32, 80, 48)
+    u8 = torch.from_numpy(synth.synth_u8_volume(32)).cuda()
+    e0 = torch_ops.pack_render_ext({})
+    assert torch.equal(ops.render_volume(torch_ops.pack_volume_params(pv), e0, u8, 1),
+                       torch.ops.mrirt.render_volume(torch_ops.pack_volume_params(pv), e0, u8, 1))
+    sp, eye, U, V, W = synth.sdf_scene()
+    blob = torch_ops.pack_sdf_params(sp, eye, U, V, W)
+    assert torch.equal(ops.render_sdf(blob, 96, 72, u8), torch.ops.mrirt.render_sdf(blob, 96, 72, u8))

@@ -208,6 +208,25 @@ def test_torch_ops_are_registered_with_shape_functions():
         torch.ops.mrirt.render_brats(blob[:-4], ext, v, None, None, None, None, None)
 
 
+def test_native_operator_library_builds_and_registers():
+    """csrc/torch_binding.cpp (the C++ PyTorch extension over the C ABI): compiles against this torch, loads without a
+    GPU, registers the three render operators, and its argument checks fire before anything touches the device."""
+    import torch
+    from mrirt import torch_ops
+    _lib.build_torch_binding()
+    ops = torch_ops.load_native()
+    for name in ("render_brats", "render_volume", "render_sdf"):
+        assert hasattr(ops, name)
+    p = synth.brats_scene(32, 64, 32, channels=1)
+    blob, ext = torch_ops.pack_brats_params(p), torch_ops.pack_render_ext({"layout": "vg"})
+    with pytest.raises(TypeError):
+        ops.render_brats(blob[:-4], ext, None, None, None, None, None, None)          # not a MrirtBratsParams
+    with pytest.raises(ValueError):
+        ops.render_brats(blob, ext, None, None, None, None, None, None)               # the enabled modality is not bound
+    with pytest.raises(TypeError):
+        ops.render_brats(blob, ext, torch.zeros(8), None, None, None, None, None)     # a host tensor as gIntensity0
+
+
 def test_bad_steps_are_refused_on_the_host_not_hung_on_the_gpu():
     """a step that is <= 0, NaN or too small to advance t in fp32 would spin the march loop
     (`while (t < t1 && T > ert) ... t += stepSize`, and the C5 count/emit loops have no transmittance exit).
