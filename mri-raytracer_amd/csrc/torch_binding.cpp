@@ -112,12 +112,41 @@ Tensor render_sdf(const Tensor& params, int64_t width, int64_t height, const Ten
     return out;
 }
 
+// logits [n, out_dim] of the packed MLP (inr/inr/model.py:21-50 for kind 0, notebooks/neumors_inr.ipynb:1165-1178 for
+// kind 1; kinds 2 / 3 take the [n, in_dim] input matrix in `feats`) through mrirt_inr_forward
+Tensor inr_forward(const Tensor& weights, const Tensor& biases, int64_t kind, int64_t num_layers, int64_t in_dim, int64_t out_dim,
+                   int64_t hidden, int64_t fourier_freqs, int64_t num_mods, double w0, const OptTensor& coords,
+                   const OptTensor& feats, int64_t n) {
+    MrirtInrDesc d;
+    std::memset(&d, 0, sizeof d);
+    d.kind = (uint32_t)kind; d.numLayers = (uint32_t)num_layers; d.inDim = (uint32_t)in_dim; d.outDim = (uint32_t)out_dim;
+    d.hidden = (uint32_t)hidden; d.fourierFreqs = (uint32_t)fourier_freqs; d.numMods = (uint32_t)num_mods; d.w0 = (float)w0;
+    const int64_t need = mrirt_inr_pack_bytes(&d);
+    TORCH_CHECK_VALUE(need > 0, "unsupported network shape");
+    TORCH_CHECK_TYPE(weights.is_cuda() && weights.scalar_type() == at::kByte && weights.numel() >= need,
+                     "weights: expected the ", need, "-byte packed image of mrirt_inr_pack_weights on the device");
+    const int64_t nb = (num_layers - 1) * hidden + ((out_dim + 31) / 32) * 32;
+    d.weights = weights.data_ptr();
+    d.biases = static_cast<const float*>(dev_ptr(biases, at::kFloat, "biases"));
+    TORCH_CHECK_VALUE(biases.numel() >= nb, "biases holds fewer than ", nb, " floats (each layer padded to a multiple of 32)");
+    const float* co = static_cast<const float*>(dev_ptr(coords, at::kFloat, "coords"));
+    const float* fe = static_cast<const float*>(dev_ptr(feats, at::kFloat, "feats"));
+    TORCH_CHECK_VALUE(kind >= 2 || (coords.has_value() && coords->numel() >= 3 * n), "coords must hold [n, 3] floats");
+    const int64_t width = kind >= 2 ? in_dim : num_mods;
+    TORCH_CHECK_VALUE(width == 0 || (feats.has_value() && feats->numel() >= width * n), "feats must hold [n, ", width, "] floats");
+    Tensor out = at::empty({ n, out_dim }, at::TensorOptions().dtype(at::kFloat).device(weights.device()));
+    check(mrirt_inr_forward(&d, co, fe, n, out.data_ptr<float>(), nullptr, current_stream()), "mrirt_inr_forward");
+    return out;
+}
+
 }  // namespace
 
 TORCH_LIBRARY(mrirt_native, m) {
     m.def("render_brats(Tensor params, Tensor ext, Tensor? vol0, Tensor? vol1, Tensor? vol2, Tensor? vol3, Tensor? labels, Tensor? preds) -> Tensor");
     m.def("render_volume(Tensor params, Tensor ext, Tensor volume, int mode) -> Tensor");
     m.def("render_sdf(Tensor params, int width, int height, Tensor like) -> Tensor");
+    m.def("inr_forward(Tensor weights, Tensor biases, int kind, int num_layers, int in_dim, int out_dim, int hidden, "
+          "int fourier_freqs, int num_mods, float w0, Tensor? coords, Tensor? feats, int n) -> Tensor");
 }
 
 // the parameter blocks are CPU tensors and the grids device tensors: no single dispatch key fits, so the
@@ -126,4 +155,5 @@ TORCH_LIBRARY_IMPL(mrirt_native, CompositeExplicitAutograd, m) {
     m.impl("render_brats", &render_brats);
     m.impl("render_volume", &render_volume);
     m.impl("render_sdf", &render_sdf);
+    m.impl("inr_forward", &inr_forward);
 }

@@ -69,6 +69,11 @@ def test_inr_forward_op_equals_api():
     api, _ = inr._forward(net, coords, feats, n, True, False)
     op = torch.ops.mrirt.inr_forward(net.weights, net.biases, inr.KIND_SIREN, 3, 7, 4, 64, 0, 4, 30.0, coords, feats, n)
     assert torch.equal(op, api)
+    from mrirt import torch_ops
+    native = torch_ops.load_native().inr_forward(net.weights, net.biases, inr.KIND_SIREN, 3, 7, 4, 64, 0, 4, 30.0, coords, feats, n)
+    assert torch.equal(native, api)
+    with pytest.raises(ValueError):
+        torch_ops.load_native().inr_forward(net.weights, net.biases, inr.KIND_SIREN, 3, 7, 4, 64, 0, 4, 30.0, coords[:10], feats, n)
 
 
 def test_native_cpp_operators_match_the_python_registered_ones():

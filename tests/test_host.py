@@ -215,7 +215,7 @@ def test_native_operator_library_builds_and_registers():
     from mrirt import torch_ops
     _lib.build_torch_binding()
     ops = torch_ops.load_native()
-    for name in ("render_brats", "render_volume", "render_sdf"):
+    for name in ("render_brats", "render_volume", "render_sdf", "inr_forward"):
         assert hasattr(ops, name)
     p = synth.brats_scene(32, 64, 32, channels=1)
     blob, ext = torch_ops.pack_brats_params(p), torch_ops.pack_render_ext({"layout": "vg"})
