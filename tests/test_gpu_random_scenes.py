@@ -189,6 +189,39 @@ def test_vga_layout_and_slab_kernel_random_cameras(env, seed):
         assert st["live_samples"] == aux["live_samples"] and st["shaded_samples"] == aux["shaded_samples"]
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_vga_modalities_overlays_and_workgroup_shapes(env, seed):
+    """VGA grids beyond the single shaded modality: 1-4 enabled modalities with weights (the pipelined, the rolling and
+    the generic kernels), seg / prediction overlays, both workgroup shapes (kernelVariant 0: 16 x 16 pixels, 2: one
+    8 x 8 packet), image sides that are not multiples of either, strict math — bit for bit against the C oracle,
+    counters included."""
+    mrirt, synth, oc = env
+    rng = np.random.default_rng(9100 + seed)
+    dims = tuple(int(v) for v in rng.integers(18, 44, 3))
+    nmod = 1 + seed % 4
+    vols = [synth.synth_volume(0, 80 + 7 * seed + m, phase=0.4 * m, dims=dims) for m in range(4)]
+    lab = synth.synth_labels(0, dims=dims)
+    pred = np.roll(lab.reshape(dims[::-1]), 3, axis=2).reshape(-1).copy()
+    cam = synth.bench_camera(radius=float(rng.choice([0.3, 1.2, 2.6])), phi_deg=float(rng.uniform(10, 170)), theta_deg=float(rng.uniform(0, 360)))
+    show_seg, show_pred = bool(seed & 2), bool(seed & 4)
+    p = synth.brats_scene(0, 0, int(rng.integers(50, 200)), dims=dims, image_hw=(int(rng.integers(11, 70)), int(rng.integers(11, 70))),
+                          channels=nmod, show_seg=show_seg, show_pred=show_pred, intensity_alpha=float(rng.choice([0.8, 12.0])),
+                          camera=cam, fov_deg=float(rng.uniform(25, 80)))
+    p["volWeight"] = tuple(float(v) for v in rng.uniform(0.3, 1.4, 4))
+    okeys = ("shadeMode", "ka", "kd", "ks", "specPow2", "gradEps")
+    grids = [mrirt.upload_grid(v, dims, "vga") for v in vols]
+    gl, gp = mrirt.upload_grid(lab, dims, "brick"), mrirt.upload_grid(pred, dims, "brick")
+    for shade in (True, False):
+        ext = dict(synth.SHADE_EXT) if shade else {}
+        ref, aux = oc.brats_main(p, vols, lab if show_seg else None, pred if show_pred else None,
+                                 {k: v for k, v in ext.items() if k in okeys}, return_aux=True)
+        for variant in (0, 2):
+            got, st = mrirt.render_brats(p, grids, labels=gl if show_seg else None, preds=gp if show_pred else None,
+                                         ext=dict(ext, layout="vga", kernelVariant=variant), stats=True)
+            assert np.array_equal(got.cpu().numpy(), ref), (seed, shade, variant, float(np.abs(got.cpu().numpy() - ref).max()))
+            assert st["live_samples"] == aux["live_samples"] and st["shaded_samples"] == aux["shaded_samples"]
+
+
 def test_slab_kernel_refuses_grids_smaller_than_a_window(env):
     mrirt, synth, oc = env
     dims = (12, 30, 30)
