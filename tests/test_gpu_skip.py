@@ -206,3 +206,29 @@ def test_second_level_leaps_are_bit_identical(layout, shade, math):
             break
     assert np.array_equal(got, want)
     assert (got >= 2).mean() > 0.3
+
+
+@pytest.mark.parametrize("layout,shade", [("vga", True), ("quad", False)])
+def test_skip_on_tile_shards_reassembles_to_the_plain_frame(layout, shade):
+    """Skipping inside the multi-GPU tile path: every rank's compact tile buffer rendered with skip=True, de-tiled,
+    is the plain whole frame bit for bit (image sides that are not multiples of the tile), counters add up."""
+    import torch
+    import mrirt
+    from mrirt import synth, tiles
+    n, w, h, tile, world = 96, 200, 150, 64, 3
+    vols, _ = head_in_air(n, channels=1)
+    p = synth.brats_scene(n, 0, 160, image_hw=(h, w), channels=1, intensity_alpha=6.0)
+    p["wl"], p["ww"] = np.float32(0.45), np.float32(0.7)
+    ext = dict(synth.SHADE_EXT) if shade else {}
+    ext.update(layout=layout)
+    g = mrirt.upload_grid(vols[0], (n, n, n), layout)
+    whole, sw = mrirt.render_brats(p, [g], ext=ext, stats=True)
+    max_local = tiles.local_tile_count(w, h, tile, 0, world)
+    gathered = torch.zeros((world, max_local, tile, tile, 4), device="cuda")
+    live = 0
+    for r in range(world):
+        part, st = mrirt.render_brats(p, [g], ext=tiles.shard_ext(ext, r, world, tile), stats=True, skip=True)
+        gathered[r, :part.shape[0]] = part
+        live += st["live_samples"]
+    assert torch.equal(mrirt.detile(gathered, w, h, tile, world), whole)
+    assert live == sw["live_samples"]
