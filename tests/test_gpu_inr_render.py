@@ -173,6 +173,11 @@ def test_c5_chunked_is_bit_identical_to_one_pass(setup, kind):
         assert a["live_samples"] == ash["live_samples"] and a["shaded_samples"] == ash["shaded_samples"]
     br = [mrirt.upload_grid(v, dims, "brick") for v in s["vols"]]
     assert torch.equal(inr.render_brats_inr(p, br, net, s["zmu"], s["zsg"], labels=gl, chunk_steps=7), ref)
+    # no seg overlay bound at all (the emission then records no seg labels)
+    p3 = dict(p, showSeg=0)
+    ref3 = inr.render_brats_inr(p3, grids, net, s["zmu"], s["zsg"], labels=None, one_pass=True)
+    assert torch.equal(inr.render_brats_inr(p3, grids, net, s["zmu"], s["zsg"], labels=None, chunk_steps=9), ref3)
+    assert not torch.equal(ref3, ref)
     # an image whose sides are not multiples of the 8 x 8 packet (lanes outside the image take part in the wave's
     # row numbering with zero samples)
     p2 = dict(p, imageSize=(37, 29))
