@@ -12,9 +12,15 @@ reference source never is.
       for the duration of the import (the four functions used are pure array expressions that
       read the same in either namespace; results are float64 where NumPy promotes, which the
       tests account for).  No reference code is copied or modified.
-  siren.npz                      : the SIREN forward exists only inside a notebook
-      (notebooks/neumors_inr.ipynb:1165-1178) and cannot be imported; this fixture is produced
-      by the oracle restatement in fp64 and is labelled "oracle-defined".
+  siren.npz                      : produced by the reference's own `siren_apply`.  That function lives
+      in a notebook code cell (notebooks/neumors_inr.ipynb, "SECTION 7" cell), not in an importable
+      module: the generator reads the cell's JSON, parses it with `ast`, takes the one `FunctionDef`
+      named siren_apply (decorator `@jit` included) and executes THAT node — nothing else of the
+      cell — in a namespace where `jnp` is numpy and `jit` is the identity (the same binding used
+      for model.py; the body is `jnp.sin`, `@` and `+` only).  Inputs are fed in fp64 (the notebook
+      sets `jax_enable_x64`) and in fp32; both outputs are stored.  Networks: 3x256 and 4x256 with
+      siren_init's zero biases, and the same with non-zero biases and a non-default w0.
+      Data only is committed; the function text never is.
   render_*.npz                   : small oracle-rendered images (oracle_np) used as regression
       anchors for both oracles and for the HIP kernels — "oracle-defined", not reference-pinned.
 
@@ -159,28 +165,49 @@ def inr_goldens():
     np.savez_compressed(HERE / "inr_fourier.npz", **out)
 
 
+def _reference_siren_apply():
+    """The notebook's own `siren_apply` (neumors_inr.ipynb:1165-1178), executed from the notebook file:
+    cell JSON -> ast -> that single FunctionDef, with `jnp` = numpy and `jit` = identity."""
+    import ast
+    import json
+    nb = json.loads((REF / "notebooks/neumors_inr.ipynb").read_text())
+    for cell in nb["cells"]:
+        src = "".join(cell.get("source", []))
+        if cell.get("cell_type") != "code" or "def siren_apply" not in src:
+            continue
+        tree = ast.parse(src)
+        fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "siren_apply"]
+        if len(fn) != 1:
+            continue
+        ns = {"jnp": np, "jit": lambda f, **k: f}
+        exec(compile(ast.Module(body=fn, type_ignores=[]), "<neumors_inr.ipynb:siren_apply>", "exec"), ns)
+        return ns["siren_apply"]
+    raise SystemExit("siren_apply not found in notebooks/neumors_inr.ipynb")
+
+
 def siren_goldens():
-    from oracle import oracle_np as onp
+    ref_apply = _reference_siren_apply()
     rng = np.random.default_rng(99)
-    out = {}
-    for tag, depth in (("s3x256", 3), ("s4x256", 4)):
+    out = {"generator": np.array("reference: notebooks/neumors_inr.ipynb siren_apply (ast-extracted, jnp=numpy)")}
+    cases = (("s3x256", 3, 30.0, False), ("s4x256", 4, 30.0, False),
+             ("s3x256b", 3, 30.0, True), ("s4x256b", 4, 30.0, True), ("s4x256w", 4, 12.5, True))
+    for tag, depth, w0, biased in cases:
         dims = [7] + [256] * depth + [4]
         params = {}
         for i in range(len(dims) - 1):
-            lim = math.sqrt(6.0 / dims[i]) / (30.0 if i == 0 else 1.0)     # neumors_inr.ipynb:1150-1163
-            params[f"l{i}"] = {"w": rng.uniform(-lim, lim, (dims[i], dims[i + 1])).astype(np.float32),
-                               "b": np.zeros(dims[i + 1], np.float32)}
+            lim = math.sqrt(6.0 / dims[i]) / (w0 if i == 0 else 1.0)     # siren_init, neumors_inr.ipynb:1150-1163
+            b = rng.uniform(-0.3, 0.3, dims[i + 1]).astype(np.float32) if biased else np.zeros(dims[i + 1], np.float32)
+            params[f"l{i}"] = {"w": rng.uniform(-lim, lim, (dims[i], dims[i + 1])).astype(np.float32), "b": b}
         x = np.concatenate([rng.uniform(-1, 1, (41, 3)), rng.uniform(0, 1, (41, 4))], axis=1).astype(np.float32)
         p64 = {k: {"w": v["w"].astype(np.float64), "b": v["b"].astype(np.float64)} for k, v in params.items()}
-        h = x.astype(np.float64)
-        for i in range(len(dims) - 2):
-            z = h @ p64[f"l{i}"]["w"]
-            h = np.sin(30.0 * z + p64[f"l{i}"]["b"]) if i == 0 else np.sin(z + p64[f"l{i}"]["b"])
-        logits = h @ p64[f"l{len(dims) - 2}"]["w"] + p64[f"l{len(dims) - 2}"]["b"]
-        assert np.abs(onp.siren_apply(params, x) - logits).max() < 1e-3
+        logits = np.asarray(ref_apply(p64, x.astype(np.float64), w0=w0))        # x64, as the notebook runs it
+        logits32 = np.asarray(ref_apply(params, x, w0=np.float32(w0)))          # the same function on fp32 arrays
+        assert logits.dtype == np.float64 and logits.shape == (41, 4)
         for k, v in params.items():
             out[f"{tag}_{k}_w"], out[f"{tag}_{k}_b"] = v["w"], v["b"]
-        out[f"{tag}_x"], out[f"{tag}_logits"] = x, logits
+        out[f"{tag}_x"], out[f"{tag}_logits"], out[f"{tag}_logits32"] = x, logits, logits32.astype(np.float32)
+        out[f"{tag}_w0"] = np.float64(w0)
+        print("siren golden", tag, "logit range", float(np.abs(logits).max()), "fp32-vs-x64", float(np.abs(logits32 - logits).max()))
     np.savez_compressed(HERE / "siren.npz", **out)
 
 

@@ -93,14 +93,16 @@ def test_predict_volume_large_agreement(env):
     assert np.array_equal(lab, got.cpu().numpy().transpose(2, 1, 0).reshape(-1))
 
 
-@pytest.mark.parametrize("tag,depth", [("s3x256", 3), ("s4x256", 4)])
-def test_siren_matches_fp64_fixture(env, tag, depth):
+@pytest.mark.parametrize("tag,depth", [("s3x256", 3), ("s4x256", 4), ("s3x256b", 3), ("s4x256b", 4), ("s4x256w", 4)])
+def test_siren_matches_reference_fixture(env, tag, depth):
+    """Logits of the notebook's own siren_apply (neumors_inr.ipynb:1165-1178; fixture generated by executing that
+    function, tests/golden/make_goldens.py), zero / non-zero biases, default / non-default w0."""
     mrirt, s = env["mrirt"], env["s"]
     params = {f"l{i}": {"w": s[f"{tag}_l{i}_w"], "b": s[f"{tag}_l{i}_b"]} for i in range(depth + 1)}
     want = s[f"{tag}_logits"]
-    got = mrirt.inr.siren_apply(params, s[f"{tag}_x"]).cpu().numpy()
+    got = mrirt.inr.siren_apply(params, s[f"{tag}_x"], w0=float(s[f"{tag}_w0"])).cpu().numpy()
     assert got.shape == want.shape
-    assert np.abs(got - want).max() <= 1e-2 * max(1.0, np.abs(want).max())          # measured 4e-3 / 5e-3
+    assert np.abs(got - want).max() <= LOGIT_REL_TOL * max(1.0, np.abs(want).max())          # measured 4e-3 / 5e-3
 
 
 def test_inr_argument_errors(env):
