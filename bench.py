@@ -6,7 +6,7 @@ Metric (BASELINE.json): Msamples/s and achieved HBM GB/s, 512^3 fp32 volume @ 10
 N = 1: BASELINE config 3 ("C3") — one fp32 channel, perspective rays, central-difference gradient +
 Blinn-Phong shading, early-ray termination (T <= 0.01), 1024 x 1024 px, on the synthetic scene of SURVEY.md
 section 8(d) (``mrirt.synth``; intensityAlpha 16 so that termination fires).
-N > 1 (launched by torch.distributed.run, one rank per GPU): BASELINE config 4 ("C4") — the same kernel and
+N > 1, one rank per GPU: BASELINE config 4 ("C4") — the same kernel and
 volume at a FIXED 2048 x 2048 image (strong scaling): 64 x 64 tiles dealt round-robin to the ranks, volume
 replicated, one RCCL gather of the compact tile buffers to rank 0 per frame (each peer's 1/N of the frame crosses
 its own xGMI link to the root once), de-tiling kernel on rank 0.
@@ -26,6 +26,14 @@ fraction falls back to the COMPULSORY bytes (volume once + framebuffer), a floor
 so in ``basis``.  SURVEY 8(d)'s algorithmic rate (cache-served taps, can exceed the HBM peak) is kept as
 ``algorithmic_GBs``; ``on_chip`` carries the two on-chip roofs that actually bind this kernel.
 
+Launching.  ``python bench.py --gpus N`` with N > 1 and no WORLD_SIZE in the environment starts the N ranks
+itself: the parent makes no HIP call (it only counts devices), runs ``python -m torch.distributed.run
+--nproc-per-node N`` on this file as a CHILD process (never an exec), relays rank 0's JSON line and exits with
+the children's status; with fewer than N devices visible it exits non-zero instead of printing an N=1 line.  Under
+torch.distributed.run (WORLD_SIZE set, as the driver launches it) each process is one rank.
+``--backend gloo --dry-run`` walks the same launcher and the same tile sharding + exchange on host tensors without
+a GPU (tests/test_bench_launcher.py).
+
 Prints ONE JSON line (rank 0).
 """
 from __future__ import annotations
@@ -34,6 +42,8 @@ import argparse
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -70,7 +80,89 @@ def parse():
     ap.add_argument("--force-exchange", action="store_true",
                     help="N=1 only: still create the RCCL group (world size 1), render compact tiles and run the "
                          "asynchronous gather + de-tiling path — a single-GPU rehearsal of the N>1 code")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend: nccl (= RCCL, the product) or gloo (host tensors; only with --dry-run)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU: every rank fills its round-robin tiles with a known pattern and runs the exchange step "
+                         "(gather to rank 0 + de-tiling) on host tensors; checks the launcher and the N>1 plumbing")
     return ap.parse_args()
+
+
+def launch_ranks(a):
+    """``--gpus N`` (N > 1) outside torch.distributed.run: start the N ranks as children of this process.
+    Nothing here touches the GPU (torch.cuda.device_count() does not initialise HIP), and the ranks are a child
+    process, not an exec of this one."""
+    if not a.dry_run:
+        import torch
+        have = torch.cuda.device_count()
+        if have < a.gpus:
+            print(f"bench.py: --gpus {a.gpus} but only {have} GPU(s) visible; refusing to report an N={have} run as N={a.gpus}",
+                  file=sys.stderr)
+            return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL needs it on this host driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_run(a, world, rank):
+    """The N>1 plumbing without a GPU: same tile ownership rule, same FrameExchange (pad to rank 0's tile count,
+    gather to rank 0, de-tile), host tensors over gloo.  Tile t's pixels hold t + 1/16ths of their index, so a
+    misplaced, missing or padded tile shows up in the assembled frame."""
+    import torch
+    import torch.distributed as dist
+    from mrirt import tiles
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    image = a.image or 2048
+    n_tiles = tiles.num_tiles(image, image, a.tile)
+
+    def tile_pattern(t):
+        px = torch.arange(a.tile * a.tile * 4, dtype=torch.float32).reshape(a.tile, a.tile, 4)
+        return px / 16.0 + float(t)
+
+    ex = tiles.FrameExchange(image, image, a.tile, torch.float32, "cpu", depth=2, dst=0)
+    owned = list(range(rank, n_tiles, world))
+    assert len(owned) == ex.n_local
+    t0 = time.perf_counter()
+    frame = None
+    for s in range(a.warmup + a.steps):
+        slot = s % 2
+        if s >= 2:
+            frame = ex.finish(slot)
+        buf = ex.local(slot)
+        for lt, t in enumerate(owned):
+            buf[lt] = tile_pattern(t)
+        ex.submit(slot)
+    for s in range(max(0, a.warmup + a.steps - 2), a.warmup + a.steps):
+        frame = ex.finish(s % 2)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    counts = [tiles.local_tile_count(image, image, a.tile, r, world) for r in range(world)]
+    if rank == 0:
+        ok = frame is not None and tuple(frame.shape) == (image, image, 4)
+        for t in range(n_tiles if ok else 0):
+            x0, y0 = tiles.tile_origin(t, image, a.tile)
+            want = tile_pattern(t)[: image - y0, : image - x0]
+            ok = ok and torch.equal(frame[y0:y0 + a.tile, x0:x0 + a.tile], want)
+        print(json.dumps({"metric": "dry run of the N-rank launcher and exchange (no GPU, no rendering)", "value": 0.0,
+                          "unit": "Msamples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                          "ms_per_step": round(elapsed / max(1, a.warmup + a.steps) * 1e3, 4), "higher_is_better": True,
+                          "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "dry_run": True,
+                          "backend": a.backend, "frame_ok": bool(ok), "tiles_per_rank": counts,
+                          "config": {"workload": f"dry run: {image}x{image} px in {a.tile}x{a.tile} tiles over {world} rank(s)"}}),
+              flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
 
 
 def measured_traffic(key):
@@ -211,18 +303,29 @@ def cpu_baseline(params, vol, ext, rows, n_image):
 
 def main():
     a = parse()
-    import torch
-    import torch.distributed as dist
-    import mrirt
-    from mrirt import synth, tiles
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if (a.backend == "gloo") != a.dry_run:
+        raise SystemExit("--backend gloo and --dry-run go together: the renderer has no CPU path")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a))                      # parent of the N ranks: no GPU call was made here
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
+    if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if a.dry_run:
+        sys.exit(dry_run(a, world, rank))
+
+    import torch
+    import torch.distributed as dist
+    import mrirt
+    from mrirt import synth, tiles
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the ray-marcher has no CPU path")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     grouped = world > 1 or a.force_exchange
