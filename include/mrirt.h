@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MRIRT_ABI_VERSION 1
+#define MRIRT_ABI_VERSION 2
 
 typedef enum MrirtStatus {
     MRIRT_OK = 0,
@@ -280,17 +280,30 @@ typedef struct MrirtInrDesc {
     const float* biases;     /* device: fp32 biases, layers concatenated, each padded to its padded out width */
 } MrirtInrDesc;
 
-/* bytes to allocate for the packed bf16 weight image of a network shape (0: unsupported shape).  Includes
- * 64 KiB of slack after the image proper: the kernel's last weight-chunk prefetch reads (and ignores) it. */
+/* bytes to allocate for the packed weight buffer of a network shape (0: unsupported shape): the bf16 MFMA image,
+ * 64 KiB of slack (the kernel's last weight-chunk prefetch reads and ignores it), the split-bf16 (hi + lo) image the
+ * near-tie refinement reads, and a 1 KiB calibration record. */
 int64_t mrirt_inr_pack_bytes(const MrirtInrDesc* desc);
-/* pack fp32 row-major [in,out] weights (device, layers concatenated unpadded) into the MFMA image.  The
- * image depends on desc->kind and desc->w0 (the SIREN's w0 / 2 pi and 1 / 2 pi are folded into it): pack
- * and forward with the same descriptor. */
+/* pack fp32 row-major [in,out] weights (device, layers concatenated unpadded) into `packed`.  The images depend on
+ * desc->kind and desc->w0 (the SIREN's w0 / 2 pi and 1 / 2 pi are folded in): pack and forward with the same
+ * descriptor.  When desc->weights == packed and desc->biases is set (the usual call), the network is also
+ * CALIBRATED here (mrirt_inr_calibrate); this synchronises `stream` once (load time). */
 int mrirt_inr_pack_weights(const MrirtInrDesc* desc, const float* w_f32, void* packed, void* stream);
+/* Near-tie calibration of a packed network: 8192 pseudo-random inputs through the bf16 pass and through the
+ * split-bf16 pass; the rms difference of the logits is stored in the calibration record.  The class outputs
+ * (argmax / predict_volume / mrirt_render_brats_inr) then re-evaluate every point whose two largest bf16 logits are
+ * closer than 3 sqrt(2) times that error with split-bf16 operands in every layer, so the stored class agrees with an
+ * fp32 evaluation except on ties ~1e-5 of the logit range apart.  Without a calibration nothing is re-evaluated. */
+int mrirt_inr_calibrate(const MrirtInrDesc* desc, void* stream);
 /* logits[n][outDim] (fp32) and/or argmax[n] (int16) for n points.
- * coords[n][3] in [-1,1]; feats[n][numMods].  Either output may be NULL.                 */
+ * coords[n][3] in [-1,1]; feats[n][numMods].  Either output may be NULL.  logits are the bf16 pass's (those of
+ * re-evaluated points, when argmax is requested too, the split-bf16 pass's). */
 int mrirt_inr_forward(const MrirtInrDesc* desc, const float* coords, const float* feats, int64_t n,
                       float* logits, int16_t* argmax, void* stream);
+/* the same with EVERY point evaluated by the split-bf16 pass (~16-bit operands in every layer, three MFMAs per
+ * product): the accuracy reference of the bf16 path, three times its matrix work */
+int mrirt_inr_forward_refined(const MrirtInrDesc* desc, const float* coords, const float* feats, int64_t n,
+                              float* logits, int16_t* argmax, void* stream);
 /* predict_volume (inr/inr/model.py:119-141): mods[M][H][W][D] fp32 -> pred[H][W][D] int16 */
 int mrirt_inr_predict_volume(const MrirtInrDesc* desc, const float* mods, const uint32_t hwd[3],
                              int16_t* pred, void* stream);

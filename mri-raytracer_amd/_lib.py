@@ -24,11 +24,12 @@ ABI_SYMBOLS = [
     "mrirt_render_brats_stream", "mrirt_brats_inr_scratch_bytes", "mrirt_render_brats_inr", "mrirt_brick_elems", "mrirt_brick_grid",
     "mrirt_unbrick_grid", "mrirt_vec4_elems", "mrirt_vga_elems", "mrirt_build_vec4_grid", "mrirt_bc4_decode", "mrirt_macro_cells", "mrirt_skip_mask_words",
     "mrirt_build_macro_max", "mrirt_build_macro_labels", "mrirt_render_brats_skip", "mrirt_render_volume", "mrirt_build_cell8", "mrirt_render_sdf", "mrirt_tiles_for_rank",
-    "mrirt_detile", "mrirt_inr_pack_bytes", "mrirt_inr_pack_weights", "mrirt_inr_forward",
+    "mrirt_detile", "mrirt_inr_pack_bytes", "mrirt_inr_pack_weights", "mrirt_inr_calibrate", "mrirt_inr_forward", "mrirt_inr_forward_refined",
     "mrirt_inr_predict_volume", "mrirt_abi_version", "mrirt_status_string", "mrirt_last_hip_error",
     "mrirt_sizeof",
 ]
 
+ABI_VERSION = 2          # MRIRT_ABI_VERSION of include/mrirt.h this binding was written against
 OK = 0
 LAYOUT_LINEAR, LAYOUT_BRICK, LAYOUT_VG, LAYOUT_QUAD, LAYOUT_VGA = 0, 1, 2, 3, 4
 MATH_STRICT, MATH_FAST = 0, 1
@@ -229,6 +230,8 @@ def lib() -> C.CDLL:
     l.mrirt_inr_pack_bytes.restype = i64
     l.mrirt_inr_pack_weights.argtypes = [C.POINTER(InrDesc), vp, vp, vp]
     l.mrirt_inr_forward.argtypes = [C.POINTER(InrDesc), vp, vp, i64, vp, vp, vp]
+    l.mrirt_inr_forward_refined.argtypes = [C.POINTER(InrDesc), vp, vp, i64, vp, vp, vp]
+    l.mrirt_inr_calibrate.argtypes = [C.POINTER(InrDesc), vp]
     l.mrirt_inr_predict_volume.argtypes = [C.POINTER(InrDesc), vp, C.POINTER(u32), vp, vp]
     l.mrirt_status_string.argtypes = [i32]
     l.mrirt_status_string.restype = C.c_char_p
@@ -236,8 +239,12 @@ def lib() -> C.CDLL:
     l.mrirt_sizeof.restype = u32
     for fn in ("mrirt_render_brats", "mrirt_render_brats_ex", "mrirt_brick_grid", "mrirt_unbrick_grid", "mrirt_build_vec4_grid",
                "mrirt_render_volume", "mrirt_render_sdf", "mrirt_detile", "mrirt_inr_pack_weights",
-               "mrirt_inr_forward", "mrirt_inr_predict_volume", "mrirt_abi_version", "mrirt_last_hip_error"):
+               "mrirt_inr_forward", "mrirt_inr_forward_refined", "mrirt_inr_calibrate", "mrirt_inr_predict_volume",
+               "mrirt_abi_version", "mrirt_last_hip_error"):
         getattr(l, fn).restype = i32
+    if l.mrirt_abi_version() != ABI_VERSION:
+        raise ImportError(f"ABI mismatch: {SO_PATH} reports version {l.mrirt_abi_version()}, this binding expects {ABI_VERSION} "
+                          "(rebuild: python -c \"import __graft_entry__ as g; g.build()\")")
     for which, st in enumerate((BratsParams, RenderExt, VolumeParams, SdfParams, InrDesc)):
         if l.mrirt_sizeof(which) != C.sizeof(st):
             raise ImportError(f"ABI mismatch: {st.__name__} is {C.sizeof(st)} B here, {l.mrirt_sizeof(which)} B in {SO_PATH}")

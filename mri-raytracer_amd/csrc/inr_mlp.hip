@@ -59,7 +59,13 @@ struct InrLayout {
     // hence scale = w0 / 2 pi (layer 0), 1 / 2 pi (hidden), 1 (head); ReLU nets: 1 everywhere.
     float scale[kMaxLayers];
     float bscale[kMaxLayers];                            // the biases' share of it: 1 / 2 pi without the w0
+    // The REFINE image (near-tie refinement, inr_refine_kernel): every layer as split bf16, fragments
+    // [out tile][k step][hi, lo] (the augmented layer 0 keeps its k-folded form [out tile][k step]); it follows
+    // the image above and its slack.  refFragOff is relative to the refine image's first fragment.
+    uint32_t refFragOff[kMaxLayers];
+    uint32_t refTotalFrags;
 };
+// one more fragment after the refine image: the calibration record (tail[0] = rms logit error of the bf16 pass)
 
 // Packed image, in fragment units:  layer 0 of a SIREN: [o][t][s][hi,lo]   every other layer: [o][t][s]
 // Augmented split (a SIREN with <= 8 inputs, i.e. the 7-input net of the notebook): the three products
@@ -93,8 +99,19 @@ static int make_layout(const MrirtInrDesc* d, InrLayout& L) {
     L.totalFrags = frag;
     L.aug0 = (d->kind == MRIRT_INR_SIREN && d->inDim <= 8) ? 1u : 0u;
     L.split0 = ((d->kind == MRIRT_INR_SIREN || d->kind == 3u) && !L.aug0) ? 1u : 0u;
+    uint32_t rf = 0;
+    for (uint32_t l = 0; l < d->numLayers; ++l) {
+        const uint32_t kt = l == 0 ? L.kt0 : d->hidden / 32, ot = (L.out[l] + 31) / 32;
+        L.refFragOff[l] = rf;
+        rf += ot * kt * 2 * ((l == 0 && L.aug0) ? 1 : 2);
+    }
+    L.refTotalFrags = rf;
     return MRIRT_OK;
 }
+// first fragment of the refine image / of the calibration record inside the packed buffer
+static inline uint32_t ref_base_frag(const InrLayout& L) { return L.totalFrags + (uint32_t)kPackSlackFrags; }
+__device__ __forceinline__ uint32_t ref_base_frag_dev(const InrLayout& L) { return L.totalFrags + (uint32_t)kPackSlackFrags; }
+static inline uint32_t tail_frag(const InrLayout& L) { return ref_base_frag(L) + L.refTotalFrags; }
 
 __device__ __forceinline__ uint16_t bf16_bits(float x) {     // round-to-nearest-even, NaN preserved by the cast
     return __builtin_bit_cast(uint16_t, (__bf16)x);
@@ -135,6 +152,54 @@ __global__ __launch_bounds__(256) void inr_pack_kernel(const float* __restrict__
     packed[(size_t)frag * 64 + lane] = q;
 }
 
+// The refine image: one thread per (fragment, lane).  Same permuted k order and the same folded scale as above;
+// fragment 2q holds the bf16 "hi" parts and 2q + 1 the "lo" parts (w - hi, rounded to bf16) of k step q.
+__global__ __launch_bounds__(256) void inr_pack_ref_kernel(const float* __restrict__ w, uint4* __restrict__ ref, InrLayout L) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t frag = gid >> 6, lane = gid & 63u;
+    if (frag >= L.refTotalFrags) return;
+    uint32_t l = 0;
+    while (l + 1 < L.numLayers && frag >= L.refFragOff[l + 1]) ++l;
+    const uint32_t kt = l == 0 ? L.kt0 : L.hidden / 32;
+    uint32_t f = frag - L.refFragOff[l];
+    const bool aug = l == 0 && L.aug0;
+    bool lo = false;
+    if (!aug) { lo = (f & 1u) != 0; f >>= 1; }
+    const uint32_t s = f & 1u, t = (f >> 1) % kt, o = (f >> 1) / kt;
+    const uint32_t r = lane & 31u, h = lane >> 5;
+    uint16_t e[8];
+#pragma unroll
+    for (uint32_t j = 0; j < 8; ++j) {
+        uint32_t k = 32 * t + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3u);
+        const uint32_t oc = 32 * o + r;
+        bool part_lo = lo;
+        if (aug) {                                       // k step 0: [W_hi ; W_hi], k step 1: [W_lo]  (as inr_pack_kernel)
+            const uint32_t kk = k & 15u, in = L.in[0];
+            part_lo = s == 1;
+            k = s == 0 ? (kk < in ? kk : (kk < 2 * in ? kk - in : 0xffffu)) : (kk < in ? kk : 0xffffu);
+        }
+        const float v = (k < L.in[l] && oc < L.out[l]) ? w[L.wOff[l] + k * L.out[l] + oc] * L.scale[l] : 0.0f;
+        const uint16_t hi = bf16_bits(v);
+        const float hif = __builtin_bit_cast(float, (uint32_t)hi << 16);
+        e[j] = part_lo ? bf16_bits(v - hif) : hi;
+    }
+    uint4 q;
+    q.x = e[0] | ((uint32_t)e[1] << 16); q.y = e[2] | ((uint32_t)e[3] << 16);
+    q.z = e[4] | ((uint32_t)e[5] << 16); q.w = e[6] | ((uint32_t)e[7] << 16);
+    ref[(size_t)frag * 64 + lane] = q;
+}
+
+// Near-tie refinement.  bf16 hidden layers leave each logit with an error of a few 1e-3 of the logit
+// range; where the two largest logits are closer than that, the argmax can differ from the fp32 reference's
+// (0.3-0.5 % of the points of a random 4-class head).  The forward kernels therefore mark every point whose top-2 gap is
+// below  tieScale x (rms logit error of this network's bf16 pass, measured once at pack time: tail[0])  by setting
+// kFlagBit in the class they store, and inr_refine_kernel re-evaluates exactly those points with split-bf16 operands
+// (hi + lo, three products, ~16 mantissa bits) in EVERY layer and stores the clean class.  The mark depends on the
+// point's own logits only, so results stay independent of batch position.
+constexpr int kFlagBit = 0x4000;          // classes are < 16: bit 14 of the int16 is free
+constexpr float kTieSigmas = 3.0f;        // mark below this many standard deviations of the gap's error (MRIRT_INR_TIE_SIGMAS overrides)
+constexpr int kCalPoints = 8192;          // calibration points (pack time)
+
 struct InrArgs {
     InrLayout L;
     uint32_t kind, K, M;
@@ -149,7 +214,18 @@ struct InrArgs {
     uint32_t H, W, D;
     float* logits;
     int16_t* argmax;
+    const float* tie;          // calibration record of the packed net (tail[0] = rms logit error); nullptr: no marking
+    float tieScale;            // mark when (best - second) < tieScale * tie[0]
+    uint32_t refineAll;        // inr_refine_kernel: every point, not only the marked ones (calibration, mrirt_inr_forward_refined)
 };
+
+// top-2 tracking for the near-tie mark: v joins (best, second); strict > keeps the first maximum (np.argmax)
+__device__ __forceinline__ void top2_push(float v, uint32_t cls, float& best, float& second, uint32_t& bestc) {
+    const bool take = v > best;
+    second = take ? best : fmaxf(second, v);
+    best = take ? v : best;
+    bestc = take ? cls : bestc;
+}
 
 constexpr int kResidentFrags = 56;    // RES: the whole packed image (<= 56 KiB) lives in LDS; two workgroups still fit a CU
 
@@ -189,6 +265,7 @@ __global__ __launch_bounds__(512) void inr_forward_kernel(const InrArgs a) {
     int64_t nPts = a.n;
     if (a.nDev != nullptr) { const int64_t nd = (int64_t)*a.nDev; nPts = nd < nPts ? nd : nPts; }
     if (nPts <= 0) return;                               // uniform: nothing was staged, no barrier is pending
+    const float tieThr = a.tie != nullptr ? a.tie[0] * a.tieScale : 0.0f;
     // Feature table (inr/inr/model.py:11-23 order: coords, per axis [sin k=1..K, cos k=1..K], modalities):
     // feature f of a point is  trig == 1 ? sin(2 pi (raw[src] * mult + phase)) : raw[src]  (trig == 2: the bf16
     // remainder raw[src] - bf16(raw[src]) of the augmented split)  with raw = (c0,c1,c2,
@@ -555,23 +632,24 @@ __global__ __launch_bounds__(512) void inr_forward_kernel(const InrArgs a) {
         }
         // np.argmax = first maximum.  Within a lane cls grows with i, so a strict > keeps the first; the
         // two lane halves hold interleaved classes, so the merge breaks ties towards the smaller class.
-        float best = -INFINITY;
+        float best = -INFINITY, second = -INFINITY;
         uint32_t bestc = 4 * h;                          // this half's first class (all -inf: class 0, as numpy)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const uint32_t cls = (i & 3) + 8 * (i >> 2) + 4 * h;
             const float v = cls < a.L.outDim ? acc[i] : -INFINITY;
-            const bool take = v > best;
-            best = take ? v : best;
-            bestc = take ? cls : bestc;
+            top2_push(v, cls, best, second, bestc);
         }
-        const float ob = __shfl_xor(best, 32);
+        const float ob = __shfl_xor(best, 32), os = __shfl_xor(second, 32);
         const uint32_t oc = __shfl_xor(bestc, 32);
-        if (ob > best || (ob == best && oc < bestc)) { best = ob; bestc = oc; }
+        if (ob > best || (ob == best && oc < bestc)) { second = fmaxf(best, os); best = ob; bestc = oc; }
+        else second = fmaxf(second, ob);
+        // near-tie mark (see kFlagBit): the refinement kernel re-evaluates this point; NaN gaps are marked too
+        const bool tie = a.tie != nullptr && !(best - second >= tieThr);
         // stored at the top of the next batch: issued here, the store would still be in flight at the
         // chunk barrier below, whose vmcnt(0) (for the DMA) would then wait out its whole HBM round trip
         pendIdx = (a.argmax && h == 0 && pidx < nPts) ? pidx : -1;
-        pendVal = (int16_t)bestc;
+        pendVal = (int16_t)(bestc | (tie ? (uint32_t)kFlagBit : 0u));
     }
     next_chunk();
     nextFrag = a.L.fragOff[0] + CH0;
@@ -653,13 +731,11 @@ __global__ __launch_bounds__(256, 1) void inr_ws_kernel(const InrArgs a) {
     constexpr int kW3Q = 4 * 4 * 64;                     // four layer-3 A fragments per wave that do not fit the registers  16 KiB
     constexpr int kW0Off = kActQ + kInQ + kPartQ + kBiasQ, kWoOff = kW0Off + kW0Q, kW3Off = kWoOff + kWoQ;
     __shared__ uint4 ldsAll[kActQ + kInQ + kPartQ + kBiasQ + kW0Q + kWoQ + kW3Q];
-    uint4* const ldsAct = ldsAll;
-    uint4* const ldsIn = ldsAll + kActQ;
-    const float4* const ldsBias = reinterpret_cast<const float4*>(ldsAll + kActQ + kInQ + kPartQ);
 
     int64_t nPts = a.n;
     if (a.nDev != nullptr) { const int64_t nd = (int64_t)*a.nDev; nPts = nd < nPts ? nd : nPts; }
     if (nPts <= 0) return;
+    const float tieThr = a.tie != nullptr ? a.tie[0] * a.tieScale : 0.0f;
 
     const uint32_t lane = threadIdx.x & 63u, r = lane & 31u, h = lane >> 5;
     const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -802,16 +878,12 @@ __global__ __launch_bounds__(256, 1) void inr_ws_kernel(const InrArgs a) {
                 for (uint32_t c = 0; c < a.L.outDim; ++c) a.logits[pidx * a.L.outDim + c] = v[c];
 #endif
             if (a.argmax != nullptr) {
-                float best = -INFINITY;
+                float best = -INFINITY, second = -INFINITY;
                 uint32_t bestc = 0;
 #pragma unroll
-                for (uint32_t c = 0; c < 4; ++c) {
-                    const float vc = c < a.L.outDim ? v[c] : -INFINITY;
-                    const bool take = vc > best;                            // strict: the first maximum
-                    best = take ? vc : best;
-                    bestc = take ? c : bestc;
-                }
-                a.argmax[pidx] = (int16_t)bestc;
+                for (uint32_t c = 0; c < 4; ++c) top2_push(c < a.L.outDim ? v[c] : -INFINITY, c, best, second, bestc);   // strict: the first maximum
+                const bool tie = a.tie != nullptr && !(best - second >= tieThr);     // near-tie mark (kFlagBit)
+                a.argmax[pidx] = (int16_t)(bestc | (tie ? (uint32_t)kFlagBit : 0u));
             }
         }
     };
@@ -914,16 +986,12 @@ __global__ __launch_bounds__(256, 1) void inr_ws_kernel(const InrArgs a) {
                         for (uint32_t c = 0; c < a.L.outDim; ++c) a.logits[pidx * a.L.outDim + c] = v[c];
 #endif
                     if (a.argmax != nullptr) {
-                        float best = -INFINITY;
+                        float best = -INFINITY, second = -INFINITY;
                         uint32_t bestc = 0;
 #pragma unroll
-                        for (uint32_t c = 0; c < 4; ++c) {
-                            const float vc = c < a.L.outDim ? v[c] : -INFINITY;
-                            const bool take = vc > best;        // strict: the first maximum
-                            best = take ? vc : best;
-                            bestc = take ? c : bestc;
-                        }
-                        a.argmax[pidx] = (int16_t)bestc;
+                        for (uint32_t c = 0; c < 4; ++c) top2_push(c < a.L.outDim ? v[c] : -INFINITY, c, best, second, bestc);   // strict: the first maximum
+                        const bool tie = a.tie != nullptr && !(best - second >= tieThr);     // near-tie mark (kFlagBit)
+                        a.argmax[pidx] = (int16_t)(bestc | (tie ? (uint32_t)kFlagBit : 0u));
                     }
                 }
             }
@@ -1008,6 +1076,369 @@ __global__ __launch_bounds__(256, 1) void inr_ws_kernel(const InrArgs a) {
     if (prevRound >= 0 && w < G) head(prevRound);
 }
 
+// =====================================================================================================
+// Near-tie refinement: the marked points (kFlagBit in the stored class) once more, with split-bf16 operands in
+// every layer — W = W_hi + W_lo, H = H_hi + H_lo (bf16 each), three MFMAs per k step (lo.hi + hi.lo + hi.hi,
+// fp32 accumulate): ~16 mantissa bits per operand instead of 8, so the class agrees with the fp32 reference except
+// on ties three orders of magnitude closer (measured: logits within 2e-5 of the range, profiles/r03_inr_refine.txt).
+// 2-3 % of the points of a random 4-class head take this path (none of a confident one), at three times the MFMA
+// work each.
+//
+// Dataflow: the streaming kernel's (transposed layers, the accumulator tile is the next layer's B operand; both
+// halves of the split stay in registers), simplified where 3 % of the work allows: 4 waves x 32 points per batch,
+// ONE wave per SIMD (the hi + lo activations of two layers are 256 registers).  Weights come from the refine image
+// one out tile (<= 32 KiB; layer 0: as many tiles as fit) at a time by LDS-DMA into a ring of four LDS buffers,
+// THREE tiles ahead of the MFMAs: a tile's MFMAs take 0.6 us and an L2 round trip more than that, so one tile in
+// flight left the kernel latency-bound (measured: 2.8 us per tile).  The DMAs span the workgroup barriers: counted
+// s_waitcnt vmcnt(2 tiles' pieces) + a raw s_barrier per tile (guide: "Pipelining across barriers"); every tile is
+// exactly PERW DMA instructions per wave (short tiles repeat their last fragment into unused slots) so that the
+// count is one immediate; the stream is cyclic (after the head comes layer 0 again), so a batch starts with its
+// first three tiles already in LDS.
+// Work list: a workgroup scans interleaved 1024-point segments of the class array for marks, collects the point
+// ids in LDS and runs a batch whenever 128 are waiting (the remainder at the end): no global compaction pass, no
+// atomics on global memory, nothing for the host to size.
+// =====================================================================================================
+constexpr int kRefWaves = 4;
+
+template <int HID, int KT0, bool SIREN, bool AUG>
+__global__ __launch_bounds__(256, 1) void inr_refine_kernel(const InrArgs a) {
+    constexpr int KT = HID / 32;
+    constexpr bool L0SPLIT = !AUG;                       // AUG: layer 0's split is folded into its k axis already
+    constexpr int NK0 = KT0 * 2, NKH = KT * 2;           // k steps of an out tile: layer 0 / the wider layers
+    constexpr int F0 = NK0 * (L0SPLIT ? 2 : 1), FH = NKH * 2;   // fragments of an out tile
+    constexpr int FMAX = F0 > FH ? F0 : FH;
+    constexpr int C0 = (FMAX / F0) < KT ? (FMAX / F0 > 0 ? FMAX / F0 : 1) : KT;   // layer-0 out tiles per DMA tile
+    static_assert(KT % C0 == 0 && C0 * F0 <= FMAX && FMAX % kRefWaves == 0, "layer-0 chunking");
+    constexpr int PERW = FMAX / kRefWaves;               // DMA instructions per wave per tile (always this many)
+    constexpr int NBUF = 4, AHEAD = NBUF - 1;            // LDS ring; tiles in flight ahead of the one being read
+    constexpr int RD = 4;                                // k steps of A fragments in registers ahead of their MFMAs
+    constexpr int kScanU = 4, kSeg = 256 * kScanU;       // a scan step reads 1024 classes
+    constexpr int kBatch = kRefWaves * 32;
+    constexpr int kListCap = kBatch + kSeg;
+    constexpr int kBiasQ = kMaxLayers * 256 / 4, kTabQ = 128, kRawQ = kRefWaves * 32 * kRawStride / 4;
+    constexpr int kWQ = NBUF * FMAX * 64;
+    __shared__ uint4 ldsAll[kWQ + kBiasQ + kTabQ + kRawQ + kListCap / 4 + 1];       // ONE LDS object (guide: a second one de-pipelines the DMA)
+    const float4* ldsBias = reinterpret_cast<const float4*>(ldsAll + kWQ);
+    float4* ldsTab = reinterpret_cast<float4*>(ldsAll + kWQ + kBiasQ);
+    float* ldsRaw = reinterpret_cast<float*>(ldsAll + kWQ + kBiasQ + kTabQ);
+    uint32_t* list = reinterpret_cast<uint32_t*>(ldsAll + kWQ + kBiasQ + kTabQ + kRawQ);
+    uint32_t* listCount = list + kListCap;
+
+    int64_t nPts = a.n;
+    if (a.nDev != nullptr) { const int64_t nd = (int64_t)*a.nDev; nPts = nd < nPts ? nd : nPts; }
+    if (nPts <= 0 || (int64_t)blockIdx.x * kSeg >= nPts) return;       // uniform
+
+    // feature table and biases: as inr_forward_kernel
+    if (a.kind < 2 && threadIdx.x < 128) {
+        const uint32_t f = threadIdx.x;
+        uint32_t src = kRawStride - 1, trig = 0;
+        float mult = 0.0f, phase = 0.0f;
+        if (f < 3) src = f;
+        else if (f < a.L.inDim) {
+            uint32_t g = f - 3;
+            if (a.kind == MRIRT_INR_FOURIER_RELU && g < 6 * a.K) {
+                const uint32_t axis = g / (2 * a.K), rem = g % (2 * a.K);
+                const bool isSin = rem < a.K;
+                src = axis; trig = 1;
+                mult = (float)((isSin ? rem : rem - a.K) + 1) * 0.5f;
+                phase = isSin ? 0.0f : 0.25f;
+            } else {
+                if (a.kind == MRIRT_INR_FOURIER_RELU) g -= 6 * a.K;
+                src = 3 + g;
+            }
+        }
+        if constexpr (AUG) {
+            const uint32_t kk = f & 15u, in = a.L.inDim;
+            src = kRawStride - 1; trig = 0;
+            if (f < 16) { if (kk < in) src = kk; else if (kk < 2 * in) { src = kk - in; trig = 2; } }
+            else if (f < 32 && kk < in) src = kk;
+        }
+        ldsTab[f] = make_float4(mult, phase, __builtin_bit_cast(float, src), __builtin_bit_cast(float, trig));
+    }
+    {
+        const uint32_t nq = (a.L.biasOff[a.L.numLayers - 1] + 32) / 4;
+        for (uint32_t i = threadIdx.x; i < nq; i += blockDim.x) {
+            uint32_t l = 0;
+            while (l + 1 < a.L.numLayers && 4 * i >= a.L.biasOff[l + 1]) ++l;
+            float4 b = reinterpret_cast<const float4*>(a.bias)[i];
+            const float sc = a.L.bscale[l];
+            b.x *= sc; b.y *= sc; b.z *= sc; b.w *= sc;
+            ldsAll[kWQ + i] = __builtin_bit_cast(uint4, b);
+        }
+    }
+    if (threadIdx.x == 0) *listCount = 0u;
+
+    const uint32_t lane = threadIdx.x & 63u, r = lane & 31u, h = lane >> 5;
+    const uint32_t waveS = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint4* __restrict__ wr = a.wpack + (size_t)ref_base_frag_dev(a.L) * 64;      // the refine image
+
+    // ---- the cyclic tile stream: layer 0 in chunks of C0 out tiles, then one out tile at a time, the head, and again ----
+    const uint32_t ldsBase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint4*)ldsAll;
+    uint32_t isLayer = 0, isTile = 0, isFrag = a.L.refFragOff[0];     // the next tile to ISSUE (scalars)
+    uint32_t ringIssue = 0, ringRead = 0;                              // ring slots: next to fill / being read
+    bool primed = false;
+    auto issue_tile = [&]() {
+        const uint32_t last = a.L.numLayers - 1;
+        const int nfr = isLayer == 0 ? C0 * F0 : FH;
+#pragma unroll
+        for (int i = 0; i < PERW; ++i) {
+            const int f = (int)waveS + i * kRefWaves;                 // fragment f of the tile -> slot f of the ring buffer
+            const int fs = f < nfr ? f : nfr - 1;                     // short tiles: repeat the last fragment (slot unused)
+            // Issued as inline asm ON PURPOSE: told about an LDS-DMA, hipcc makes the next ds_read whose address it cannot
+            // tell apart from the DMA's target (a ring slot chosen at run time) wait vmcnt(0) — the whole look-ahead drained
+            // once per tile (seen in the ISA of the builtin form).  The waits for these loads are the counted ones in
+            // tile_done(); hipcc's own counted waits (for the batch's input loads) can only over-wait, never under-wait.
+            const char* src = reinterpret_cast<const char*>(wr) + ((size_t)(isFrag + (uint32_t)fs) << 10) + (lane << 4);
+            const uint32_t dst = __builtin_amdgcn_readfirstlane(ldsBase + ((ringIssue * FMAX + (uint32_t)f) << 10));   // wave-uniform; the DMA adds lane * 16
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(dst) : "memory", "m0");
+        }
+        isFrag += (uint32_t)nfr;
+        const uint32_t tilesHere = isLayer == 0 ? (uint32_t)(KT / C0) : (isLayer == last ? 1u : (uint32_t)KT);
+        if (++isTile == tilesHere) { isTile = 0; if (++isLayer > last) { isLayer = 0; isFrag = a.L.refFragOff[0]; } }
+        ringIssue = ringIssue + 1 == NBUF ? 0u : ringIssue + 1;
+    };
+    // end of a tile: this wave's pieces of the NEXT tile have landed (the two after it may still be in flight), its own
+    // LDS reads of this tile have retired; after the barrier that holds for every wave
+    auto tile_done = [&]() {
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PERW * (AHEAD - 1)) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        ringRead = ringRead + 1 == NBUF ? 0u : ringRead + 1;
+    };
+    auto frag_at = [&](int f) { return __builtin_bit_cast(bf16x8, ldsAll[(ringRead * FMAX + f) * 64 + lane]); };
+
+    // ---- one batch: list[off .. off + m) ---------------------------------------------------------------------
+    auto run_batch = [&](uint32_t off, uint32_t m) {
+        const uint32_t slot = waveS * 32 + r;
+        const bool valid = slot < m;
+        const int64_t p = (int64_t)list[off + (valid ? slot : 0u)];
+
+        // layer-0 B operands (the streaming kernel's load_inputs, for an arbitrary point id)
+        bf16x8 xin_hi[KT0][2], xin_lo[KT0][2];
+        if (a.kind < 2) {
+            float* raw = ldsRaw + waveS * 32 * kRawStride + r;
+            if (h == 0) {
+                float c[3], mm[kMaxMods];
+                const uint32_t M = a.M;
+                if (a.volume) {
+                    const uint32_t k = (uint32_t)(p % a.D), j = (uint32_t)((p / a.D) % a.W), i = (uint32_t)(p / ((int64_t)a.D * a.W));
+                    c[0] = (float)(((double)i / (double)(a.H - 1)) * 2.0 - 1.0);
+                    c[1] = (float)(((double)j / (double)(a.W - 1)) * 2.0 - 1.0);
+                    c[2] = (float)(((double)k / (double)(a.D - 1)) * 2.0 - 1.0);
+                    const size_t hwd = (size_t)a.H * a.W * a.D;
+#pragma unroll
+                    for (uint32_t g = 0; g < kMaxMods; ++g) mm[g] = M ? a.feats[(size_t)(g < M ? g : M - 1) * hwd + p] : 0.0f;
+                } else {
+                    c[0] = a.coords[p * 3 + 0]; c[1] = a.coords[p * 3 + 1]; c[2] = a.coords[p * 3 + 2];
+#pragma unroll
+                    for (uint32_t g = 0; g < kMaxMods; ++g) mm[g] = M ? a.feats[p * (int64_t)M + (g < M ? g : M - 1)] : 0.0f;
+                }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) raw[32 * k] = c[k];
+#pragma unroll
+                for (int k = 0; k < kMaxMods; ++k) raw[32 * (3 + k)] = mm[k];
+                raw[32 * (kRawStride - 1)] = 0.0f;
+            }
+#pragma unroll
+            for (int t = 0; t < KT0; ++t)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float4 d = ldsTab[32 * t + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3)];
+                        const float x = raw[32 * __builtin_bit_cast(uint32_t, d.z)];
+                        const uint32_t mode = __builtin_bit_cast(uint32_t, d.w);
+                        const float v = mode == 1u ? __builtin_amdgcn_sinf(__builtin_fmaf(x, d.x, d.y)) : x;
+                        const __bf16 hi = (__bf16)v;
+                        const __bf16 lo = (__bf16)(v - (float)hi);
+                        xin_hi[t][s][j] = (AUG && mode == 2u) ? lo : hi;
+                        xin_lo[t][s][j] = lo;
+                    }
+                }
+        } else {
+#pragma unroll
+            for (int t = 0; t < KT0; ++t)
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const uint32_t f = 32 * t + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3);
+                        float v = a.feats[p * (int64_t)a.L.inDim + (f < a.L.inDim ? f : 0u)];
+                        v = f < a.L.inDim ? v : 0.0f;
+                        const __bf16 hi = (__bf16)v;
+                        xin_hi[t][s][j] = hi;
+                        xin_lo[t][s][j] = (__bf16)(v - (float)hi);
+                    }
+        }
+        // the inputs are in registers (the compiler has waited for every ordinary load above, and with it for any DMA
+        // still in flight); from here to the end of the batch the only vector-memory operations in flight are DMAs
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!primed) {                                   // first batch of this workgroup: start the stream
+#pragma unroll
+            for (int d = 0; d < AHEAD; ++d) issue_tile();
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PERW * (AHEAD - 1)) : "memory");
+            primed = true;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                    // first tile in LDS for every wave (and table + biases + list on the first batch)
+
+        bf16x8 Hc_hi[KT][2], Hc_lo[KT][2], Hn_hi[KT][2], Hn_lo[KT][2];
+        auto bias_tile = [&](uint32_t layerOff, int o) {
+            f32x16 acc;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 b = ldsBias[(layerOff + 32 * o + 8 * g + 4 * h) >> 2];
+                acc[4 * g + 0] = b.x; acc[4 * g + 1] = b.y; acc[4 * g + 2] = b.z; acc[4 * g + 3] = b.w;
+            }
+            return acc;
+        };
+        // activation, then the split of the result: hi = bf16(x), lo = bf16(x - hi)
+        auto activate = [&](const f32x16& acc, int o) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float x = acc[i];
+                if constexpr (SIREN) x = __builtin_amdgcn_sinf(x);
+                else x = fmaxf(x, 0.0f);
+                const __bf16 hi = (__bf16)x;
+                Hn_hi[o][i >> 3][i & 7] = hi;
+                Hn_lo[o][i >> 3][i & 7] = (__bf16)(x - (float)hi);
+            }
+        };
+        auto act_one = [&](const f32x16& acc, int o, int i) {
+            float x = acc[i];
+            if constexpr (SIREN) x = __builtin_amdgcn_sinf(x);
+            else x = fmaxf(x, 0.0f);
+            const __bf16 hi = (__bf16)x;
+            Hn_hi[o][i >> 3][i & 7] = hi;
+            Hn_lo[o][i >> 3][i & 7] = (__bf16)(x - (float)hi);
+        };
+        // the three products of one k step (small terms first)
+        auto mfma3 = [&](f32x16& acc, const bf16x8& whi, const bf16x8& wlo, const bf16x8& bhi, const bf16x8& blo) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo, bhi, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi, blo, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi, bhi, acc, 0, 0, 0);
+        };
+
+        // ---- layer 0 -----------------------------------------------------------------------------------------
+        {
+            const uint32_t b0 = a.L.biasOff[0];
+#pragma unroll
+            for (int c = 0; c < KT / C0; ++c) {
+                issue_tile();
+#pragma unroll
+                for (int oo = 0; oo < C0; ++oo) {
+                    const int o = c * C0 + oo;
+                    f32x16 acc = bias_tile(b0, o);
+#pragma unroll
+                    for (int q = 0; q < NK0; ++q) {
+                        const int t = q >> 1, s2 = q & 1;
+                        if constexpr (L0SPLIT) mfma3(acc, frag_at(oo * F0 + 2 * q), frag_at(oo * F0 + 2 * q + 1), xin_hi[t][s2], xin_lo[t][s2]);
+                        else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_at(oo * F0 + q), xin_hi[t][s2], acc, 0, 0, 0);
+                    }
+                    activate(acc, o);
+                }
+                tile_done();
+            }
+        }
+        // ---- hidden layers -----------------------------------------------------------------------------------
+        for (uint32_t l = 1; l + 1 < a.L.numLayers; ++l) {
+#pragma unroll
+            for (int t = 0; t < KT; ++t) { Hc_hi[t][0] = Hn_hi[t][0]; Hc_hi[t][1] = Hn_hi[t][1]; Hc_lo[t][0] = Hn_lo[t][0]; Hc_lo[t][1] = Hn_lo[t][1]; }
+            const uint32_t bl = a.L.biasOff[l];
+            f32x16 accPrev;                              // finished tile o - 1: activated and split under tile o's MFMAs
+#pragma unroll
+            for (int o = 0; o < KT; ++o) {
+                issue_tile();
+                f32x16 acc = bias_tile(bl, o);
+                bf16x8 rhi[RD], rlo[RD];
+#pragma unroll
+                for (int d = 0; d < RD; ++d) if (d < NKH) { rhi[d] = frag_at(2 * d); rlo[d] = frag_at(2 * d + 1); }
+#pragma unroll
+                for (int q = 0; q < NKH; ++q) {
+                    mfma3(acc, rhi[q % RD], rlo[q % RD], Hc_hi[q >> 1][q & 1], Hc_lo[q >> 1][q & 1]);
+                    if (q + RD < NKH) { rhi[q % RD] = frag_at(2 * (q + RD)); rlo[q % RD] = frag_at(2 * (q + RD) + 1); }
+                    if (o > 0) {
+#pragma unroll
+                        for (int i = q * 16 / NKH; i < (q + 1) * 16 / NKH; ++i) act_one(accPrev, o - 1, i);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);   // keep the slices where they are written: one per k step
+                }
+                accPrev = acc;
+                tile_done();
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) act_one(accPrev, KT - 1, i);     // the layer's last tile
+        }
+        // ---- head ----------------------------------------------------------------------------------------------
+        {
+            issue_tile();
+            f32x16 acc = bias_tile(a.L.biasOff[a.L.numLayers - 1], 0);
+            bf16x8 rhi[RD], rlo[RD];
+#pragma unroll
+            for (int d = 0; d < RD; ++d) if (d < NKH) { rhi[d] = frag_at(2 * d); rlo[d] = frag_at(2 * d + 1); }
+#pragma unroll
+            for (int q = 0; q < NKH; ++q) {
+                mfma3(acc, rhi[q % RD], rlo[q % RD], Hn_hi[q >> 1][q & 1], Hn_lo[q >> 1][q & 1]);
+                if (q + RD < NKH) { rhi[q % RD] = frag_at(2 * (q + RD)); rlo[q % RD] = frag_at(2 * (q + RD) + 1); }
+            }
+            float best = -INFINITY, second = -INFINITY;
+            uint32_t bestc = 4 * h;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const uint32_t cls = (i & 3) + 8 * (i >> 2) + 4 * h;
+                top2_push(cls < a.L.outDim ? acc[i] : -INFINITY, cls, best, second, bestc);
+            }
+            const float ob = __shfl_xor(best, 32);
+            const uint32_t oc = __shfl_xor(bestc, 32);
+            if (ob > best || (ob == best && oc < bestc)) { best = ob; bestc = oc; }
+            tile_done();                                 // (before the stores: they would count against the DMA budget)
+            if (a.logits != nullptr && valid) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const uint32_t cls = (i & 3) + 8 * (i >> 2) + 4 * h;
+                    if (cls < a.L.outDim) a.logits[p * a.L.outDim + cls] = acc[i];
+                }
+            }
+            if (a.argmax != nullptr && valid && h == 0) a.argmax[p] = (int16_t)bestc;       // the clean class
+        }
+    };
+
+    // ---- scan for marks, batch as they accumulate ------------------------------------------------------------
+    uint32_t cnt = 0;                                    // replicated in every thread: entries waiting in `list`
+    __syncthreads();
+    for (int64_t seg = blockIdx.x; seg * kSeg < nPts; seg += gridDim.x) {
+        const int64_t base = seg * kSeg;
+        int16_t v[kScanU];
+#pragma unroll
+        for (int u = 0; u < kScanU; ++u) {
+            const int64_t idx = base + u * 256 + threadIdx.x;
+            v[u] = (!a.refineAll && idx < nPts) ? a.argmax[idx] : (int16_t)0;
+        }
+#pragma unroll
+        for (int u = 0; u < kScanU; ++u) {
+            const int64_t idx = base + u * 256 + threadIdx.x;
+            const bool marked = idx < nPts && (a.refineAll != 0u || (v[u] & kFlagBit) != 0);
+            const uint64_t mk = __ballot(marked);
+            uint32_t wbase = 0;
+            if (lane == 0 && mk != 0) wbase = atomicAdd(listCount, (uint32_t)__popcll(mk));
+            wbase = __shfl(wbase, 0);
+            if (marked) list[wbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u))] = (uint32_t)idx;
+        }
+        __syncthreads();
+        cnt = *listCount;
+        const bool lastSeg = (seg + gridDim.x) * kSeg >= nPts;       // after the last segment the remainder goes as a short batch
+        while (cnt >= (uint32_t)kBatch || (lastSeg && cnt > 0)) {    // (ONE call site: the batch body is inlined once)
+            const uint32_t m = cnt < (uint32_t)kBatch ? cnt : (uint32_t)kBatch;
+            run_batch(cnt - m, m);
+            cnt -= m;
+        }
+        __syncthreads();                                 // every wave has read its list entries
+        if (threadIdx.x == 0) *listCount = cnt;
+        __syncthreads();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the stream's look-ahead DMAs: nothing may be in flight at exit
+}
+
 // nets the weight-stationary kernel takes: the 7-input SIREN with four 256-wide layers and <= 4 classes, points mode
 static bool ws_eligible(const InrArgs& a) {
     return a.kind == MRIRT_INR_SIREN && a.L.aug0 && a.L.hidden == 256 && a.L.numLayers == 5 && a.L.outDim <= 4 &&
@@ -1065,8 +1496,7 @@ static int launch_inr_kt0(const InrArgs& a, hipStream_t s) {
     return MRIRT_OK;
 }
 
-static int launch_inr(const InrArgs& a, hipStream_t s) {
-    if (a.n <= 0) return MRIRT_OK;
+static int launch_inr_main(const InrArgs& a, hipStream_t s) {
     if (ws_eligible(a) && getenv("MRIRT_INR_NO_WS") == nullptr) return launch_inr_ws(a, s);
     if ((a.n + kInrWaves * 32 - 1) / (kInrWaves * 32) >= (1ll << 31)) return MRIRT_ERR_ARG;
     switch (a.L.hidden) {
@@ -1075,6 +1505,52 @@ static int launch_inr(const InrArgs& a, hipStream_t s) {
         case 128: return launch_inr_kt0<128>(a, s);
         default: return launch_inr_kt0<256>(a, s);
     }
+}
+
+template <int HID>
+static int launch_refine_hid(const InrArgs& a, hipStream_t s) {
+    const bool siren = a.kind == MRIRT_INR_SIREN || a.kind == 3u;
+    void (*kern)(const InrArgs) = a.L.kt0 == 1
+        ? (siren ? (a.L.aug0 ? inr_refine_kernel<HID, 1, true, true> : inr_refine_kernel<HID, 1, true, false>)
+                 : inr_refine_kernel<HID, 1, false, false>)
+        : (siren ? inr_refine_kernel<HID, 4, true, false> : inr_refine_kernel<HID, 4, false, false>);
+    int dev = 0, cus = 0;
+    MRIRT_HIP(hipGetDevice(&dev));
+    MRIRT_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const int64_t segs = (a.n + 1023) / 1024, nres = cus > 0 ? cus : 256;       // one workgroup per CU (512 registers per wave)
+    hipLaunchKernelGGL(kern, dim3((uint32_t)(segs < nres ? segs : nres)), dim3(kRefWaves * 64), 0, s, a);
+    MRIRT_HIP(hipGetLastError());
+    return MRIRT_OK;
+}
+
+// the split-bf16 pass over the marked points of a.argmax (or over every point: a.refineAll)
+static int launch_refine(const InrArgs& a, hipStream_t s) {
+    if (a.n >= (1ll << 32)) return MRIRT_ERR_ARG;        // point ids travel as 32-bit words
+    switch (a.L.hidden) {
+        case 32: return launch_refine_hid<32>(a, s);
+        case 64: return launch_refine_hid<64>(a, s);
+        case 128: return launch_refine_hid<128>(a, s);
+        default: return launch_refine_hid<256>(a, s);
+    }
+}
+
+// near-tie marking + refinement can be switched off for A/B measurements (the classes are then the bf16 pass's)
+static bool refine_enabled() { return getenv("MRIRT_INR_NO_REFINE") == nullptr; }
+static float tie_sigmas() {
+    const char* e = getenv("MRIRT_INR_TIE_SIGMAS");
+    const float v = e ? (float)atof(e) : 0.0f;
+    return v > 0.0f ? v : kTieSigmas;
+}
+
+static int launch_inr(InrArgs a, hipStream_t s) {
+    if (a.n <= 0) return MRIRT_OK;
+    const bool refine = a.argmax != nullptr && a.tie != nullptr && refine_enabled() && !a.refineAll;
+    if (a.refineAll) return launch_refine(a, s);
+    if (!refine) a.tie = nullptr;
+    else a.tieScale = tie_sigmas() * 1.41421356f;        // the gap of two logits carries two errors
+    int rc = launch_inr_main(a, s);
+    if (rc != MRIRT_OK || !refine) return rc;
+    return launch_refine(a, s);
 }
 
 static int fill_args(const MrirtInrDesc* d, InrArgs& a) {
@@ -1086,6 +1562,8 @@ static int fill_args(const MrirtInrDesc* d, InrArgs& a) {
     a.bias = d->biases;
     a.coords = nullptr; a.feats = nullptr; a.n = 0; a.nDev = nullptr; a.volume = 0; a.H = a.W = a.D = 1;
     a.logits = nullptr; a.argmax = nullptr;
+    a.tie = reinterpret_cast<const float*>(a.wpack + (size_t)tail_frag(a.L) * 64);     // written by mrirt_inr_pack_weights
+    a.tieScale = 0.0f; a.refineAll = 0;
     return MRIRT_OK;
 }
 
@@ -1108,19 +1586,127 @@ using namespace mrirt;
 extern "C" int64_t mrirt_inr_pack_bytes(const MrirtInrDesc* desc) {
     InrLayout L;
     if (make_layout(desc, L) != MRIRT_OK) return 0;
-    return (int64_t)(L.totalFrags + kPackSlackFrags) * 1024;    // slack: the last chunk's DMA over-fetch (never used)
+    // main image + slack (the last chunk's DMA over-fetch, never used) + refine image + calibration record
+    return (int64_t)(tail_frag(L) + 1) * 1024;
 }
+
+namespace mrirt {
+
+__device__ __forceinline__ uint32_t cal_hash(uint32_t x) {         // lowbias32
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ float cal_uniform(uint32_t i) { return (float)(cal_hash(i) >> 8) * (1.0f / 16777216.0f); }
+
+// calibration inputs: coords ~ U(-1, 1); modalities ~ the sum of four uniforms, centred and scaled to unit variance
+// (z-scored intensities, brats_viewer.py:281-287); raw-x kinds: every input ~ U(-1, 1)
+__global__ void inr_cal_inputs_kernel(float* __restrict__ coords, float* __restrict__ feats, uint32_t n, uint32_t featW, uint32_t raw) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    for (uint32_t k = 0; k < 3; ++k) coords[i * 3 + k] = 2.0f * cal_uniform(i * 131u + k) - 1.0f;
+    for (uint32_t k = 0; k < featW; ++k) {
+        const uint32_t sd = 0x9e3779b9u + (i * 257u + k) * 4u;
+        feats[(size_t)i * featW + k] = raw ? 2.0f * cal_uniform(sd) - 1.0f
+                                           : (cal_uniform(sd) + cal_uniform(sd + 1) + cal_uniform(sd + 2) + cal_uniform(sd + 3) - 2.0f) * 1.7320508f;
+    }
+}
+
+// tail[0] = rms over points and classes of (bf16 pass - split-bf16 pass), [1] = max |logit|, [2] = max |difference|, [3] = points
+__global__ __launch_bounds__(256) void inr_cal_reduce_kernel(const float* __restrict__ la, const float* __restrict__ lb, uint32_t count,
+                                                             float points, float* __restrict__ tail) {
+    __shared__ double ssq[256];
+    __shared__ float smx[256], sme[256];
+    double q = 0.0;
+    float mx = 0.0f, me = 0.0f;
+    for (uint32_t i = threadIdx.x; i < count; i += 256) {
+        const float d = la[i] - lb[i];
+        q += (double)d * (double)d;
+        mx = fmaxf(mx, fabsf(lb[i]));
+        me = fmaxf(me, fabsf(d));
+    }
+    ssq[threadIdx.x] = q; smx[threadIdx.x] = mx; sme[threadIdx.x] = me;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            ssq[threadIdx.x] += ssq[threadIdx.x + o];
+            smx[threadIdx.x] = fmaxf(smx[threadIdx.x], smx[threadIdx.x + o]);
+            sme[threadIdx.x] = fmaxf(sme[threadIdx.x], sme[threadIdx.x + o]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        tail[0] = (float)sqrt(ssq[0] / (double)count);
+        tail[1] = smx[0]; tail[2] = sme[0]; tail[3] = points;
+    }
+}
+
+// Measures, once per packed network, the error scale of its bf16 pass: kCalPoints pseudo-random inputs through the
+// forward kernel and through the split-bf16 kernel, rms difference of the logits -> the calibration record.
+static int calibrate(const MrirtInrDesc* d, hipStream_t s) {
+    InrArgs a;
+    int rc = fill_args(d, a);
+    if (rc != MRIRT_OK) return rc;
+    const bool raw = d->kind >= 2;
+    const uint32_t featW = raw ? d->inDim : (d->numMods > 0 ? d->numMods : 1u), n = kCalPoints;
+    const size_t fl = (size_t)n * (3 + featW + 2 * d->outDim);
+    float* buf = nullptr;
+    MRIRT_HIP(hipMalloc(reinterpret_cast<void**>(&buf), fl * sizeof(float)));
+    float* coords = buf; float* feats = coords + (size_t)n * 3; float* la = feats + (size_t)n * featW; float* lb = la + (size_t)n * d->outDim;
+    hipLaunchKernelGGL(inr_cal_inputs_kernel, dim3((n + 255) / 256), dim3(256), 0, s, coords, feats, n, featW, raw ? 1u : 0u);
+    if (raw) a.M = d->inDim;
+    a.coords = raw ? nullptr : coords; a.feats = feats; a.n = n;
+    a.logits = la; a.tie = nullptr;
+    rc = launch_inr_main(a, s);                          // the bf16 pass (logits only)
+    if (rc == MRIRT_OK) { a.logits = lb; a.refineAll = 1; rc = launch_refine(a, s); }
+    if (rc == MRIRT_OK) {
+        float* tail = const_cast<float*>(reinterpret_cast<const float*>(a.wpack + (size_t)tail_frag(a.L) * 64));
+        hipLaunchKernelGGL(inr_cal_reduce_kernel, dim3(1), dim3(256), 0, s, la, lb, n * d->outDim, (float)n, tail);
+        if (hipGetLastError() != hipSuccess) rc = MRIRT_ERR_LAUNCH;
+    }
+    const hipError_t e = hipStreamSynchronize(s);        // load time: the scratch is freed before returning
+    (void)hipFree(buf);
+    if (e != hipSuccess) return hip_fail(e);
+    return rc;
+}
+
+}  // namespace mrirt
 
 extern "C" int mrirt_inr_pack_weights(const MrirtInrDesc* desc, const float* w_f32, void* packed, void* stream) {
     InrLayout L;
     int rc = make_layout(desc, L);
     if (rc != MRIRT_OK) return rc;
     if (!w_f32 || !packed) return MRIRT_ERR_NULL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
     const uint32_t threads = L.totalFrags * 64;
-    hipLaunchKernelGGL(inr_pack_kernel, dim3((threads + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       w_f32, static_cast<uint4*>(packed), L);
+    hipLaunchKernelGGL(inr_pack_kernel, dim3((threads + 255) / 256), dim3(256), 0, s, w_f32, static_cast<uint4*>(packed), L);
     MRIRT_HIP(hipGetLastError());
+    uint4* ref = static_cast<uint4*>(packed) + (size_t)ref_base_frag(L) * 64;
+    hipLaunchKernelGGL(inr_pack_ref_kernel, dim3((L.refTotalFrags * 64 + 255) / 256), dim3(256), 0, s, w_f32, ref, L);
+    MRIRT_HIP(hipGetLastError());
+    // the calibration record: zero (= nothing is marked) until the biases are known
+    MRIRT_HIP(hipMemsetAsync(static_cast<uint4*>(packed) + (size_t)tail_frag(L) * 64, 0, 1024, s));
+    if (desc->weights == packed && desc->biases != nullptr) return calibrate(desc, s);
     return MRIRT_OK;
+}
+
+extern "C" int mrirt_inr_calibrate(const MrirtInrDesc* desc, void* stream) {
+    if (!desc || !desc->weights || !desc->biases) return MRIRT_ERR_NULL;
+    return calibrate(desc, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int mrirt_inr_forward_refined(const MrirtInrDesc* desc, const float* coords, const float* feats, int64_t n,
+                                         float* logits, int16_t* argmax, void* stream) {
+    InrArgs a;
+    int rc = fill_args(desc, a);
+    if (rc != MRIRT_OK) return rc;
+    if (n < 0) return MRIRT_ERR_ARG;
+    const bool needCoords = desc->kind < 2, needFeats = desc->kind >= 2 || desc->numMods > 0;
+    if ((needCoords && !coords) || (needFeats && !feats)) return MRIRT_ERR_NULL;
+    if (!logits && !argmax) return MRIRT_ERR_NULL;
+    if (desc->kind >= 2) a.M = desc->inDim;
+    a.coords = desc->kind < 2 ? coords : nullptr;
+    a.feats = feats; a.n = n; a.logits = logits; a.argmax = argmax; a.refineAll = 1;
+    return launch_inr(a, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int mrirt_inr_forward(const MrirtInrDesc* desc, const float* coords, const float* feats, int64_t n,

@@ -127,14 +127,32 @@ def pack_mlp(params, kind: int, fourier_freqs: int = 0, num_mods: int = 0, w0: f
     return PackedMLP(d, packed, biases, int(d.inDim), int(d.outDim))
 
 
-def _forward(net: PackedMLP, coords, feats, n: int, want_logits: bool, want_argmax: bool):
+def _forward(net: PackedMLP, coords, feats, n: int, want_logits: bool, want_argmax: bool, refined: bool = False):
     dev = net.weights.device
     logits = torch.empty((n, net.out_dim), dtype=torch.float32, device=dev) if want_logits else None
     arg = torch.empty(n, dtype=torch.int16, device=dev) if want_argmax else None
-    rc = _lib.lib().mrirt_inr_forward(C.byref(net.desc), _ptr(coords), _ptr(feats), n, _ptr(logits), _ptr(arg),
-                                      _stream_ptr(None))
-    _lib.check(rc, "mrirt_inr_forward")
+    fn = _lib.lib().mrirt_inr_forward_refined if refined else _lib.lib().mrirt_inr_forward
+    rc = fn(C.byref(net.desc), _ptr(coords), _ptr(feats), n, _ptr(logits), _ptr(arg), _stream_ptr(None))
+    _lib.check(rc, "mrirt_inr_forward_refined" if refined else "mrirt_inr_forward")
     return logits, arg
+
+
+def classify(net: PackedMLP, coords, feats, refined: bool = False, want_logits: bool = False):
+    """argmax class (int16) of every point — the bf16 MFMA pass, with the points whose two largest logits are within
+    the network's calibrated bf16 error re-evaluated in split bf16 (``mrirt_inr_forward``); ``refined=True`` evaluates
+    every point in split bf16 (``mrirt_inr_forward_refined``).  Raw-x networks (KIND_RAW_*) take ``coords=None``."""
+    dev = _require_gpu()
+    f = _dev_f32(feats, dev)
+    c = _dev_f32(coords, dev) if coords is not None else None
+    logits, arg = _forward(net, c, f, f.shape[0], want_logits, True, refined)
+    return (arg, logits) if want_logits else arg
+
+
+def calibration(net: PackedMLP) -> Dict[str, float]:
+    """The calibration record ``mrirt_inr_pack_weights`` measured for this network: rms / max difference between the
+    bf16 pass's logits and the split-bf16 pass's over 8192 pseudo-random inputs, and the largest |logit| seen."""
+    tail = net.weights[-1024:].view(torch.float32)[:4].cpu().numpy()
+    return dict(rms_error=float(tail[0]), max_logit=float(tail[1]), max_error=float(tail[2]), points=int(tail[3]))
 
 
 def _dev_f32(x, dev):

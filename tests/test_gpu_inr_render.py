@@ -2,8 +2,8 @@
 sample.  Checked in three layers so the bf16 classifier does not blur the exact parts:
   1. sample counts and emitted MLP inputs == the oracle's, exactly (fp32 / fp64 coordinate);
   2. compositing with the GPU's own class stream == the oracle compositing with that stream;
-  3. end to end vs the all-fp32 oracle: classes agree except near logit ties, images agree on
-     almost every pixel, and the disagreement is bounded by one overlay step."""
+  3. end to end vs the all-fp32 oracle: classes agree on >= 99.9 % of the samples (near logit ties of the bf16 pass are
+     re-evaluated in split bf16), >= 99.5 % of the pixels are within 1e-4, the rest within one overlay step."""
 import numpy as np
 import pytest
 
@@ -74,19 +74,25 @@ def test_c5_layers(setup, layout):
     logits = onp.apply_mlp(s["mlp"], x)
     want = np.argmax(logits, axis=-1)
     agree = (classes == want)
-    assert agree.mean() >= 0.995, agree.mean()                       # measured 0.996-0.998 (profiles/r02_inr_accuracy.txt)
+    assert agree.mean() >= 0.999, agree.mean()                       # SURVEY 8c; near-ties are re-evaluated in split bf16
     top2 = np.sort(logits[~agree], axis=-1)[:, -2:]
-    assert np.all(top2[:, 1] - top2[:, 0] <= 1e-2 * np.abs(logits).max()), "every disagreement is a near-tie"
+    assert np.all(top2[:, 1] - top2[:, 0] <= 1e-4 * np.abs(logits).max()), "a remaining disagreement is a tie at the fp32 oracle's own noise level"
     ref = onp.brats_main_inr(p, s["vols"], s["mlp"], s["K"], s["zmu"], s["zsg"], labels=s["lab"])
     d = np.abs(img - ref)[..., :3].max(axis=-1)
-    # a ray is exact unless one of its ~40 samples sits on a logit near-tie (<1 % of samples do)
+    # a ray is exact unless one of its ~40 samples flipped
     flipped_rays = sum(1 for o, c in zip(offsets, counts.reshape(-1)) if c and not agree[o:o + c].all()) / counts.size
     assert (d > 1e-4).mean() <= flipped_rays + 1e-9, "only rays holding a flipped class may differ"
-    # ... which IS the floor on exact pixels: 1 - P(a ray holds a near-tie sample).  With ~0.3 % of the samples flipping and
-    # ~25-40 composited samples per marching ray that is ~0.9-0.97 (0.967 measured in round 1); a fixed floor would only
-    # restate the measured flip rate, so the bound on it is the sample-level agreement above.
-    assert flipped_rays <= 0.15 and d.mean() < 2e-3
-    assert d.max() <= 0.25          # one flipped overlay step: alpha*T*|lut.rgb| with alpha = 1 - e^{-0.9*dt*1.5}
+    assert (d <= 1e-4).mean() >= 0.995, (d <= 1e-4).mean()          # BASELINE's 1e-4 on >= 99.5 % of the pixels
+    assert d.max() <= 0.25          # a flipped overlay step: alpha*T*|lut.rgb| with alpha = 1 - e^{-0.9*dt*1.5}
+    # the same frame with the refinement switched off shows what it buys (and that the switch works)
+    import os
+    os.environ["MRIRT_INR_NO_REFINE"] = "1"
+    try:
+        raw, araw = mrirt.inr.render_brats_inr(p, grids, net, s["zmu"], s["zsg"], labels=gl, return_aux=True, one_pass=True)
+    finally:
+        del os.environ["MRIRT_INR_NO_REFINE"]
+    agree_raw = araw["classes"].cpu().numpy() == want
+    assert agree_raw.mean() < agree.mean() and agree_raw.mean() >= 0.99
 
 
 def test_c5_lattice_coordinates_are_predict_volumes(setup):
@@ -249,8 +255,12 @@ def test_c5_as_named_siren_4x256_512x512_256_samples():
     agree = have == want
     top2 = np.sort(rec["l"][seen][~agree], axis=-1)[:, -2:]
     scale = np.abs(rec["l"][seen]).max()
-    assert agree.mean() >= 0.995, agree.mean()                       # measured 0.9967
-    assert np.all(top2[:, 1] - top2[:, 0] <= 1e-2 * scale), "every disagreement is a near-tie"   # measured 6.5e-3
+    assert agree.mean() >= 0.999, agree.mean()                       # SURVEY 8c (0.9967 before the near-tie refinement)
+    assert np.all(top2[:, 1] - top2[:, 0] <= 1e-4 * scale), "a remaining disagreement is a tie at the fp32 oracle's own noise level"
+    # pixels of the band against the all-fp32 oracle (its own classes): BASELINE's 1e-4 on >= 99.5 % of them
+    ref_fp32 = onp.brats_main_inr(p, vols, siren, 0, zmu, zsg, labels=lab, kind="siren", rows=(r0, r1))
+    dpx = np.abs(got_band - ref_fp32)[..., :3].max(axis=-1)
+    assert (dpx <= 1e-4).mean() >= 0.995, (dpx <= 1e-4).mean()
     print(f"C5 SIREN band: {seen.sum()} samples, argmax agreement {agree.mean():.5f}, worst tie gap "
           f"{(top2[:, 1] - top2[:, 0]).max() / scale if len(top2) else 0:.2e} of range; "
           f"frame: {a['queries']} queries chunked vs {a0['queries']} whole-ray, {a['live_samples']} live")
