@@ -237,8 +237,14 @@ typedef struct MrirtSkip {
     const float* macroUb[4];      /* per modality: mrirt_build_macro_max output, or NULL (modality unused)   */
     const uint32_t* macroSeg;     /* mrirt_build_macro_labels of gLabels (needed when showSeg)               */
     const uint32_t* macroPred;    /* ... of gPreds (needed when showPred)                                    */
-    uint32_t* mask;               /* scratch, mrirt_skip_mask_words(dims) uint32 (8^3 macro-cell bits, then the byte
-                                     maps of the empty-radius transform): rewritten by every launch            */
+    uint32_t* mask;               /* scratch of maskWords uint32 (8^3 macro-cell bits, then the byte maps of the
+                                     empty-radius transform); written by a launch unless mapReady             */
+    uint32_t maskWords;           /* size of `mask` in words: must be >= mrirt_skip_mask_words(dims) (checked: a caller
+                                     built against an older formula gets MRIRT_ERR_ARG, not device writes past its buffer) */
+    uint32_t mapReady;            /* != 0: `mask` still holds the map a previous launch built from the SAME dims, window
+                                     (ww, wl), gamma, volEnabled, volWeight, showSeg / showPred, math mode and summaries —
+                                     the four pre-pass launches are skipped (a viewer frame changes the camera, not these).
+                                     The caller orders that launch before this one (same stream, or an event).            */
 } MrirtSkip;
 int64_t mrirt_macro_cells(const uint32_t dims[3]);
 int64_t mrirt_skip_mask_words(const uint32_t dims[3]);

@@ -97,7 +97,8 @@ class InrDesc(C.Structure):
 
 class Skip(C.Structure):
     """MrirtSkip: macro-cell summaries + mask scratch for exact empty-space skipping."""
-    _fields_ = [("macroUb", C.c_void_p * 4), ("macroSeg", C.c_void_p), ("macroPred", C.c_void_p), ("mask", C.c_void_p)]
+    _fields_ = [("macroUb", C.c_void_p * 4), ("macroSeg", C.c_void_p), ("macroPred", C.c_void_p), ("mask", C.c_void_p),
+                ("maskWords", u32), ("mapReady", u32)]
 
 
 class MrirtError(RuntimeError):

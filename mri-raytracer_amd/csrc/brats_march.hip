@@ -169,7 +169,11 @@ struct Stage {
     template <bool STRICT, bool GAMMA1>
     __device__ __forceinline__ void consume(const K1Args& a, const float rd[3], RayState& r) const {
         using Mm = M<STRICT>;
-        if (SKIP && empty) { ++r.nLive; return; }
+        if (SKIP && empty) {
+            ++r.nLive;
+            if (a.debugFlags & 1u) ++r.nShaded;          // diagnostic (kernelVariant bit 7): stats[1] = shaded + samples NOT fetched
+            return;
+        }
         float v = 0.0f, g[3] = { 0.0f, 0.0f, 0.0f };
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {                      // ascending modality order, as the shader
@@ -233,6 +237,7 @@ __device__ __forceinline__ void march_skip(const K1Args& a, const WaveGrid<LAYOU
             for (uint32_t i = 0; i < n; ++i) {                       // wave-uniform trip count
                 const bool go = alive && t < t1;
                 r.nLive += go ? 1u : 0u;
+                if (a.debugFlags & 1u) r.nShaded += go ? 1u : 0u;    // (diagnostic, as in Stage::consume)
                 t = go ? t + a.stepSize : t;
             }
             alive = alive && t < t1;
@@ -918,7 +923,8 @@ using namespace mrirt;
 // kernelVariant toggles (experiments; 0 = library default):
 //   bit 0: row-major instead of Morton lane order      bit 1: flip 64- / 256-thread workgroups (256 is the default on VGA)
 //   bit 2: no software pipelining                      bits 3-5: XCD band height (prepare(); bits 4-5 = 1: 16 px)
-//   bit 6: the LDS-staged kernel of brats_slab.hip     bit 7: ... counts its LDS-served samples in stats[1]
+//   bit 6: the LDS-staged kernel of brats_slab.hip     bit 7: ... counts its LDS-served samples in stats[1]; the skipping
+//                                                             kernels: the samples they did NOT fetch (flagged or leapt)
 //   bit 8: skipping one step at a time (no leaps); in the slab kernel: count ring misses
 extern "C" int mrirt_render_brats_ex(const MrirtBratsParams* p, const MrirtRenderExt* ext,
                                      const void* const vol[4], const void* labels, const void* preds,
@@ -957,12 +963,30 @@ extern "C" int mrirt_render_brats_skip(const MrirtBratsParams* p, const MrirtRen
     // window width and gamma (pow(0, g) = 0), non-negative weights (monotone sum), a bound for every enabled
     // modality and a label summary for every shown overlay.  Otherwise: the ordinary launch.
     bool ok = skip->mask != nullptr && p->ww > 0.0f && p->gamma > 0.0f && a.nch >= 1;
+    // ... and only where the launch below has a SKIP kernel: the pipelined kernel on VG / VGA grids with one modality or on
+    // QUAD grids (launch()), STRICT with gamma == 1 or FAST (launch_pipe()).  Anything else would pay the four pre-pass
+    // launches for a kernel that ignores the map — and, with several shaded modalities, lose the rolling kernel to the
+    // generic one (launch() takes a non-null skipDist as "not the rolling kernel": 0.87 vs 0.81 ms).
+    {
+        const bool wide = a.grid.wide != 0;
+        const bool layoutOk = ((cfg.layout == MRIRT_LAYOUT_VG && !wide) || cfg.layout == MRIRT_LAYOUT_VGA) ? a.nch == 1
+                            : (cfg.layout == MRIRT_LAYOUT_QUAD && !wide && !cfg.shade);
+        const bool mathOk = cfg.math == MRIRT_MATH_FAST || p->gamma == 1.0f;
+        ok = ok && cfg.pipe && !cfg.slab && layoutOk && mathOk;
+    }
     for (int k = 0; k < 3; ++k) ok = ok && (p->dims[k] + 7) / 8 <= 256;   // macro coordinates travel through 8-bit wave reductions
     for (uint32_t c = 0; c < a.nch && ok; ++c)
         ok = skip->macroUb[a.chan[c]] != nullptr && a.weight[a.chan[c]] >= 0.0f;
     if (p->showSeg != 0 && !skip->macroSeg) ok = false;
     if (p->showPred != 0 && !skip->macroPred) ok = false;
-    if (ok) {
+    if (ok && (int64_t)skip->maskWords < mrirt_skip_mask_words(p->dims)) return MRIRT_ERR_ARG;
+    if (ok && skip->mapReady != 0) {
+        // the scratch already holds this configuration's map (the caller vouches for it: MrirtSkip::mapReady)
+        const uint32_t mx = (p->dims[0] + 7) / 8, my = (p->dims[1] + 7) / 8, mz = (p->dims[2] + 7) / 8, cells = mx * my * mz;
+        a.skipDist = reinterpret_cast<uint8_t*>(skip->mask + ((cells + 63u) / 64u) * 2u);
+        a.mX = mx; a.mXY = mx * my; a.mY = my; a.mZ = mz;
+        a.leap = (a.debugFlags & 2u) == 0u ? 1u : 0u;
+    } else if (ok) {
         SkipArgs k;
         const uint32_t mx = (p->dims[0] + 7) / 8, my = (p->dims[1] + 7) / 8, mz = (p->dims[2] + 7) / 8;
         k.cells = mx * my * mz; k.nch = a.nch;

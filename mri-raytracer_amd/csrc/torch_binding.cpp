@@ -7,6 +7,7 @@
 // libmrirt.so, whose kernels do the work.  Replaces kernel.dispatch of inr/viewer/brats_viewer.py:431-442,
 // scripts/volumeRendering/app.py:350-358 and scripts/raymarch/app.py:212-223 for callers that want operators.
 #include <ATen/ATen.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <torch/library.h>
 
@@ -34,6 +35,20 @@ const void* dev_ptr(const OptTensor& t, at::ScalarType dt, const char* what) {
     if (!t.has_value()) return nullptr;
     TORCH_CHECK_TYPE(t->is_cuda() && t->scalar_type() == dt && t->is_contiguous(), what, ": expected a contiguous device tensor of the right dtype");
     return t->data_ptr();
+}
+
+// The kernels are launched on the current stream OF THE TENSORS' DEVICE: every operator first checks that all its
+// device tensors live on one GPU, then makes that GPU current for the allocation of the output and for the stream
+// lookup (with device 0 current and the grids on device 1 the launch would otherwise go to device 0's
+// stream with device-1 pointers).
+using DeviceGuard = c10::hip::OptionalHIPGuardMasqueradingAsCUDA;
+
+void same_device(std::optional<at::Device>& dev, const OptTensor& t, const char* what) {
+    if (!t.has_value()) return;
+    TORCH_CHECK_TYPE(t->is_cuda(), what, ": expected a device tensor");
+    if (!dev.has_value()) dev = t->device();
+    TORCH_CHECK_VALUE(t->device() == *dev, what, " is on ", t->device(), " but another operand is on ", *dev,
+                      ": every device tensor of one call must live on the same GPU");
 }
 
 void* current_stream() { return (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream(); }
@@ -71,7 +86,7 @@ Tensor render_brats(const Tensor& params, const Tensor& ext, const OptTensor& vo
     std::optional<at::Device> dev;
     for (int m = 0; m < 4; ++m) {
         vp[m] = dev_ptr(*vols[m], at::kFloat, names[m]);
-        if (vols[m]->has_value() && !dev.has_value()) dev = (*vols[m])->device();
+        same_device(dev, *vols[m], names[m]);
         TORCH_CHECK_VALUE(P.volEnabled[m] == 0 || (vols[m]->has_value() && (*vols[m])->numel() >= need),
                           names[m], " is enabled but holds fewer than ", need, " elements");
     }
@@ -80,6 +95,9 @@ Tensor render_brats(const Tensor& params, const Tensor& ext, const OptTensor& vo
     const void* prd = dev_ptr(preds, at::kInt, "gPreds");
     TORCH_CHECK_VALUE(P.showSeg == 0 || (labels.has_value() && labels->numel() >= lneed), "showSeg is set but gLabels is missing or too small");
     TORCH_CHECK_VALUE(P.showPred == 0 || (preds.has_value() && preds->numel() >= lneed), "showPred is set but gPreds is missing or too small");
+    same_device(dev, labels, "gLabels");
+    same_device(dev, preds, "gPreds");
+    DeviceGuard guard(*dev);
     const auto dt = E.outFormat == MRIRT_OUT_RGBA16F ? at::kHalf : at::kFloat;
     Tensor out = at::empty(out_shape(P.imageSize[0], P.imageSize[1], E), at::TensorOptions().dtype(dt).device(*dev));
     check(mrirt_render_brats_ex(&P, &E, vp, lab, prd, out.data_ptr(), (int64_t)P.imageSize[0], nullptr, current_stream()),
@@ -96,6 +114,7 @@ Tensor render_volume(const Tensor& params, const Tensor& ext, const Tensor& volu
     const void* vol = dev_ptr(volume, want, "gVolumeU8");
     const int64_t nvox = (int64_t)P.volDim[0] * P.volDim[1] * P.volDim[2];
     TORCH_CHECK_VALUE(volume.numel() >= nvox, "gVolumeU8 holds fewer than ", nvox, " voxels");
+    DeviceGuard guard(volume.device());
     const auto dt = E.outFormat == MRIRT_OUT_RGBA16F ? at::kHalf : at::kFloat;
     Tensor out = at::empty(out_shape(P.imageSize[0], P.imageSize[1], E), at::TensorOptions().dtype(dt).device(volume.device()));
     check(mrirt_render_volume(&P, &E, vol, (uint32_t)mode, out.data_ptr(), (int64_t)P.imageSize[0], nullptr, current_stream()),
@@ -107,6 +126,7 @@ Tensor render_volume(const Tensor& params, const Tensor& ext, const Tensor& volu
 Tensor render_sdf(const Tensor& params, int64_t width, int64_t height, const Tensor& like) {
     const MrirtSdfParams P = unblob<MrirtSdfParams>(params, "MrirtSdfParams");
     TORCH_CHECK_TYPE(like.is_cuda(), "like: expected a device tensor");
+    DeviceGuard guard(like.device());
     Tensor out = at::empty({ height, width, 4 }, at::TensorOptions().dtype(at::kFloat).device(like.device()));
     check(mrirt_render_sdf(&P, (uint32_t)width, (uint32_t)height, out.data_ptr<float>(), width, current_stream()), "mrirt_render_sdf");
     return out;
@@ -134,6 +154,11 @@ Tensor inr_forward(const Tensor& weights, const Tensor& biases, int64_t kind, in
     TORCH_CHECK_VALUE(kind >= 2 || (coords.has_value() && coords->numel() >= 3 * n), "coords must hold [n, 3] floats");
     const int64_t width = kind >= 2 ? in_dim : num_mods;
     TORCH_CHECK_VALUE(width == 0 || (feats.has_value() && feats->numel() >= width * n), "feats must hold [n, ", width, "] floats");
+    std::optional<at::Device> dev = weights.device();
+    same_device(dev, biases, "biases");
+    same_device(dev, coords, "coords");
+    same_device(dev, feats, "feats");
+    DeviceGuard guard(*dev);
     Tensor out = at::empty({ n, out_dim }, at::TensorOptions().dtype(at::kFloat).device(weights.device()));
     check(mrirt_inr_forward(&d, co, fe, n, out.data_ptr<float>(), nullptr, current_stream()), "mrirt_inr_forward");
     return out;

@@ -6,6 +6,7 @@ without a GPU (or without the built library) these functions raise.
 """
 from __future__ import annotations
 
+import collections
 import contextlib
 import ctypes as C
 from dataclasses import dataclass
@@ -222,12 +223,21 @@ def _bind_brats(params, intensities, labels, preds, ext, dev, pred_stream: bool 
 
 
 _last_skip_mask: Optional[torch.Tensor] = None
+_SKIP_MAPS: "collections.OrderedDict[tuple, torch.Tensor]" = collections.OrderedDict()
+_SKIP_MAPS_MAX = 8
+skip_map_builds = 0              # how many launches built a map (tests: a repeated frame must not)
 
 
-def _bind_skip(P, intensities, labels, preds, dev):
-    """MrirtSkip for one call: the macro summaries of the bound Grid objects + a mask scratch of this call's own
-    (a few hundred KB from the caching allocator, on the launch stream: the pre-pass rewrites it on every launch, so a
-    scratch shared between calls would be overwritten under a march still reading it on another stream)."""
+def _bind_skip(P, E, intensities, labels, preds, dev, stream):
+    """MrirtSkip for one call: the macro summaries of the bound Grid objects + the mask / empty-radius map scratch.
+
+    The map depends on the grids' summaries and on (dims, ww, wl, gamma, volEnabled, volWeight, showSeg, showPred, math) —
+    not on the camera — so a viewer's frames reuse it: scratches are cached per (those values, the bound summary
+    tensors, device, stream) and a hit sets ``mapReady`` (the library then skips the four pre-pass launches, ~30 us of
+    a 160 us viewer frame).  The stream is part of the key because the map was written by a launch on that stream and
+    nothing else orders a reader on another stream after it; the summary tensors are held by the entry, so a key can never
+    name freed-and-reused memory."""
+    global _last_skip_mask, skip_map_builds
     S = _lib.Skip()
     keep = []
     for m in range(4):
@@ -245,11 +255,24 @@ def _bind_skip(P, intensities, labels, preds, dev):
             keep.append(g.macro)
     d = (C.c_uint32 * 3)(*[int(v) for v in P.dims])
     words = int(_lib.lib().mrirt_skip_mask_words(d))
-    global _last_skip_mask
-    mask = torch.empty(words, dtype=torch.int32, device=dev)
-    S.mask = mask.data_ptr()
+    sid = stream if stream is not None else torch.cuda.current_stream()
+    sid = sid.cuda_stream if hasattr(sid, "cuda_stream") else int(sid)
+    key = (tuple(int(v) for v in P.dims), float(P.ww), float(P.wl), float(P.gamma), tuple(int(v) for v in P.volEnabled),
+           tuple(float(v) for v in P.volWeight), int(P.showSeg) != 0, int(P.showPred) != 0, int(E.math),
+           tuple(t.data_ptr() for t in keep), dev.index, sid)
+    hit = _SKIP_MAPS.get(key)
+    if hit is not None:
+        _SKIP_MAPS.move_to_end(key)
+        mask, S.mapReady = hit[0], 1
+    else:
+        mask = torch.empty(words, dtype=torch.int32, device=dev)
+        _SKIP_MAPS[key] = (mask, list(keep))            # holds the summaries: their addresses cannot be recycled under the key
+        while len(_SKIP_MAPS) > _SKIP_MAPS_MAX:
+            _SKIP_MAPS.popitem(last=False)
+        skip_map_builds += 1
+    S.mask, S.maskWords = mask.data_ptr(), words
     keep.append(mask)
-    _last_skip_mask = mask          # inspection hook (tests read the fraction of skippable cells); never reused
+    _last_skip_mask = mask          # inspection hook (tests read the fraction of skippable cells)
     return S, keep
 
 
@@ -279,7 +302,7 @@ def render_brats(params: Mapping[str, Any], intensities: Sequence[Optional[Union
         vp = (C.c_void_p * 4)(*[C.c_void_p(t.data_ptr()) if t is not None else None for t in vols])
         st = torch.zeros(2, dtype=torch.int64, device=dev) if stats else None
         if skip:
-            S, keep = _bind_skip(P, intensities, labels, preds, dev)
+            S, keep = _bind_skip(P, E, intensities, labels, preds, dev, stream)
             rc = _lib.lib().mrirt_render_brats_skip(C.byref(P), C.byref(E), vp, _ptr(lab), _ptr(prd), C.byref(S), _ptr(o),
                                                     pitch, _ptr(st), _stream_ptr(stream))
             _lib.check(rc, "mrirt_render_brats_skip")

@@ -74,6 +74,25 @@ def _ptr(t: Optional[torch.Tensor]) -> C.c_void_p:
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(None)
 
 
+def _one_device(named: Sequence) -> torch.device:
+    """The GPU every device tensor of a call lives on (raises when they disagree).  The launch then happens with that
+    GPU current (``torch.cuda.device``): the stream is ITS current stream and the output is allocated on it — with
+    device 0 current and the grids on device 1 the kernel would otherwise be enqueued on device 0 with device-1
+    pointers."""
+    dev = None
+    for what, t in named:
+        if t is None:
+            continue
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise ValueError(f"{what} is on {t.device} but another operand is on {dev}: every device tensor of one call "
+                             "must live on the same GPU")
+    if dev is None:
+        raise ValueError("no device tensor bound")
+    return dev
+
+
 def _dev_flat(t: Optional[torch.Tensor], dtype, what: str) -> Optional[torch.Tensor]:
     if t is None:
         return None
@@ -123,12 +142,13 @@ def render_brats(params: torch.Tensor, ext: torch.Tensor, vol0: Optional[torch.T
         raise ValueError("showSeg is set but gLabels is missing or too small")
     if P.showPred != 0 and (prd is None or prd.numel() < lneed):
         raise ValueError("showPred is set but gPreds is missing or too small")
-    dev = next(v.device for v in vols if v is not None)
+    dev = _one_device([(f"gIntensity{m}", v) for m, v in enumerate(vols)] + [("gLabels", lab), ("gPreds", prd)])
     dt = torch.float16 if E.outFormat == _lib.OUT_RGBA16F else torch.float32
-    out = torch.empty(_out_shape(int(P.imageSize[0]), int(P.imageSize[1]), E), dtype=dt, device=dev)
     vp = (C.c_void_p * 4)(*[C.c_void_p(v.data_ptr()) if v is not None else None for v in vols])
-    rc = _lib.lib().mrirt_render_brats_ex(C.byref(P), C.byref(E), vp, _ptr(lab), _ptr(prd), _ptr(out),
-                                          int(P.imageSize[0]), None, _stream())
+    with torch.cuda.device(dev):
+        out = torch.empty(_out_shape(int(P.imageSize[0]), int(P.imageSize[1]), E), dtype=dt, device=dev)
+        rc = _lib.lib().mrirt_render_brats_ex(C.byref(P), C.byref(E), vp, _ptr(lab), _ptr(prd), _ptr(out),
+                                              int(P.imageSize[0]), None, _stream())
     _lib.check(rc, "mrirt_render_brats_ex")
     return out
 
@@ -157,9 +177,10 @@ def render_volume(params: torch.Tensor, ext: torch.Tensor, volume: torch.Tensor,
     if vol.numel() < nvox:
         raise ValueError(f"gVolumeU8 holds {vol.numel()} < {nvox} voxels")
     dt = torch.float16 if E.outFormat == _lib.OUT_RGBA16F else torch.float32
-    out = torch.empty(_out_shape(int(P.imageSize[0]), int(P.imageSize[1]), E), dtype=dt, device=vol.device)
-    rc = _lib.lib().mrirt_render_volume(C.byref(P), C.byref(E), _ptr(vol), int(mode), _ptr(out), int(P.imageSize[0]),
-                                        None, _stream())
+    with torch.cuda.device(vol.device):
+        out = torch.empty(_out_shape(int(P.imageSize[0]), int(P.imageSize[1]), E), dtype=dt, device=vol.device)
+        rc = _lib.lib().mrirt_render_volume(C.byref(P), C.byref(E), _ptr(vol), int(mode), _ptr(out), int(P.imageSize[0]),
+                                            None, _stream())
     _lib.check(rc, "mrirt_render_volume")
     return out
 
@@ -176,8 +197,11 @@ def _(params, ext, volume, mode):
 def render_sdf(params: torch.Tensor, width: int, height: int, like: torch.Tensor) -> torch.Tensor:
     """raymarch_cs (scripts/raymarch/raymarch.slang:60-99); ``like`` only names the device."""
     P = _unblob(params, _lib.SdfParams)
-    out = torch.empty((height, width, 4), dtype=torch.float32, device=like.device)
-    rc = _lib.lib().mrirt_render_sdf(C.byref(P), int(width), int(height), _ptr(out), int(width), _stream())
+    if not like.is_cuda:
+        raise TypeError("like: expected a device tensor")
+    with torch.cuda.device(like.device):
+        out = torch.empty((height, width, 4), dtype=torch.float32, device=like.device)
+        rc = _lib.lib().mrirt_render_sdf(C.byref(P), int(width), int(height), _ptr(out), int(width), _stream())
     _lib.check(rc, "mrirt_render_sdf")
     return out
 
@@ -215,8 +239,10 @@ def inr_forward(weights: torch.Tensor, biases: torch.Tensor, kind: int, num_laye
     if width > 0 and (fe is None or fe.numel() < width * n):
         raise ValueError(f"feats must hold [n, {width}] floats")
     d.weights, d.biases = weights.data_ptr(), bz.data_ptr()
-    out = torch.empty((n, out_dim), dtype=torch.float32, device=weights.device)
-    rc = _lib.lib().mrirt_inr_forward(C.byref(d), _ptr(co), _ptr(fe), int(n), _ptr(out), None, _stream())
+    dev = _one_device([("weights", weights), ("biases", bz), ("coords", co), ("feats", fe)])
+    with torch.cuda.device(dev):
+        out = torch.empty((n, out_dim), dtype=torch.float32, device=dev)
+        rc = _lib.lib().mrirt_inr_forward(C.byref(d), _ptr(co), _ptr(fe), int(n), _ptr(out), None, _stream())
     _lib.check(rc, "mrirt_inr_forward")
     return out
 

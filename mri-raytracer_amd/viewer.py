@@ -86,7 +86,7 @@ class BraTSViewer:
     def load_arrays(self, mods: Dict[str, np.ndarray], zooms=(1.0, 1.0, 1.0), seg: Optional[np.ndarray] = None) -> None:
         """The body of load_dir for in-memory (X,Y,Z) arrays keyed by 'T1n','T1c','T2w','FLAIR'."""
         if not mods:
-            raise RuntimeError("No modality volumes found.")
+            raise RuntimeError("none of the four modality volumes (t1 / t1ce / t2 / flair) could be loaded")
         dims = None
         self.raw_volumes, self.buffers = {}, {k: self._empty_float for k in MOD_ORDER}
         for key, data in mods.items():
@@ -94,7 +94,7 @@ class BraTSViewer:
             if dims is None:
                 dims = d
             elif not np.all(d == dims):
-                raise RuntimeError("Dim mismatch")
+                raise RuntimeError(f"modality {key} has dims {tuple(int(v) for v in d)}, the others {tuple(int(v) for v in dims)}")
             self.raw_volumes[key] = norm          # the viewer keeps the NORMALISED array (brats_viewer.py:205,218,227)
             self.buffers[key] = self._create_buffer(lin)
         self.vol_dims = dims.astype(np.uint32)
@@ -120,7 +120,7 @@ class BraTSViewer:
                     mods[key] = data
                     zooms = z if zooms is None else zooms
         if not mods:
-            raise RuntimeError("No modality volumes found.")
+            raise RuntimeError("none of the four modality volumes (t1 / t1ce / t2 / flair) could be loaded")
         self.load_arrays(mods, zooms, seg)
 
     def frame_volume(self) -> None:
@@ -140,7 +140,7 @@ class BraTSViewer:
         cfg = config_raw.get("config", config_raw)
         k = int(cfg.get("FOURIER_FREQS", cfg.get("fourier_freqs", 10)))
         if not all(m in self.raw_volumes for m in MOD_ORDER):
-            raise RuntimeError("Missing required modalities.")
+            raise RuntimeError("the INR prepass needs all four modalities loaded")
         mods = np.stack([volume.zscore_nonzero(self.raw_volumes[m]) for m in MOD_ORDER], axis=0)
         pred, _ = inr_model.predict_volume(params, {"mods": mods, "seg": None}, fourier_freqs=k)
         self.pred_buffer = shim.Buffer(self.device, pred.numel(), 4)

@@ -69,7 +69,7 @@ def mask_to_u8(data: np.ndarray, mode: str = "occupancy") -> np.ndarray:
         for value, code in ((1.0, 85), (2.0, 170), (4.0, 255)):
             u8[np.isclose(vol, value)] = code
     else:
-        raise ValueError(f"Unknown mask_mode '{mode}'. Use 'occupancy' or 'labels'.")
+        raise ValueError(f"mask_mode must be 'occupancy' or 'labels', got {mode!r}")
     return flatten_xyz(u8)
 
 
@@ -79,7 +79,7 @@ def bc4_decode(bc: bytes, width: int, height: int, depth: int) -> np.ndarray:
     bw, bh = (width + 3) // 4, (height + 3) // 4
     want = depth * bw * bh * 8
     if len(bc) != want:
-        raise RuntimeError(f"BC4 data size mismatch: {len(bc)} vs {want}")
+        raise RuntimeError(f"a {depth}x{height}x{width} BC4 volume is {want} bytes of 8-byte blocks, got {len(bc)}")
     blk = np.frombuffer(bc, dtype=np.uint8).reshape(depth, bh, bw, 8)
     r0 = blk[..., 0].astype(np.int32)
     r1 = blk[..., 1].astype(np.int32)
@@ -117,7 +117,7 @@ def bc4_decode_device(bc, width: int, height: int, depth: int, stream=None):
         bc = np.frombuffer(bytes(bc), dtype=np.uint8).copy()
     t = torch.as_tensor(bc)
     if t.dtype != torch.uint8 or t.numel() != want:
-        raise RuntimeError(f"BC4 data size mismatch: {t.numel()} vs {want}")
+        raise RuntimeError(f"a {depth}x{height}x{width} BC4 volume is {want} bytes of 8-byte blocks, got {t.numel()}")
     t = t.reshape(-1).cuda().contiguous()
     out = torch.empty(depth * height * width, dtype=torch.uint8, device=t.device)
     s = C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)

@@ -93,35 +93,67 @@ def test_skip_matches_oracle_and_switches_itself_off():
         mrirt.render_brats(p, [vols[0]], labels=labels, skip=True)
 
 
-def test_skip_speeds_up_a_sparse_volume():
-    """Not a benchmark — a guard that skipping actually skips: on a 256^3 blob-in-air the skipping launch
-    must be clearly faster than the plain one."""
+def test_skip_really_skips_and_the_map_is_cached_across_frames():
+    """A guard that skipping actually skips, on counters rather than on a stopwatch: with
+    kernelVariant bit 7 the skipping kernels add the samples they did NOT fetch (flagged cell, or leapt over) to
+    stats[1]; on a 256^3 blob-in-air most samples must be of that kind.  And the empty-radius map depends on window /
+    weights / overlays, not on the camera: the second frame of an orbit must reuse it (no pre-pass launches)."""
     import torch
     import mrirt
-    from mrirt import synth
+    from mrirt import synth, render
     n, image = 256, 512
     vols, _ = head_in_air(n, seed=1)
     p = synth.brats_scene(n, image, 384, channels=1, intensity_alpha=2.0)
     p["wl"], p["ww"] = np.float32(0.45), np.float32(0.7)
     ext = dict(synth.SHADE_EXT, layout="vg")
     g = mrirt.upload_grid(vols[0], (n, n, n), "vg")
-    out = torch.empty((image, image, 4), device="cuda")
+    plain, st0 = mrirt.render_brats(p, [g], ext=ext, stats=True)
+    builds = render.skip_map_builds
+    skipped, st1 = mrirt.render_brats(p, [g], ext=ext, stats=True, skip=True)
+    assert torch.equal(plain, skipped) and st0 == st1
+    assert render.skip_map_builds == builds + 1
+    _, st2 = mrirt.render_brats(p, [g], ext=dict(ext, kernelVariant=128), stats=True, skip=True)
+    unfetched = st2["shaded_samples"] - st0["shaded_samples"]
+    assert st2["live_samples"] == st0["live_samples"]
+    print(f"\n256^3 blob in air, 512^2 x 384 steps: {unfetched} of {st0['live_samples']} samples not fetched "
+          f"({unfetched / st0['live_samples']:.3f})")
+    assert unfetched >= 0.5 * st0["live_samples"]
+    assert render.skip_map_builds == builds + 1, "same window / weights / overlays: the map is reused"
+    # another camera: still the same map; the frame is still the plain kernel's
+    cam = mrirt.OrbitalCamera(initial_radius=3.0, initial_phi=np.radians(60), initial_theta=np.radians(-40))
+    eye, U, V, W = cam.get_basis()
+    q = dict(p, eye=eye, U=U, V=V, W=W)
+    a = mrirt.render_brats(q, [g], ext=ext)
+    b = mrirt.render_brats(q, [g], ext=ext, skip=True)
+    assert torch.equal(a, b) and render.skip_map_builds == builds + 1
+    # a different window is a different map
+    q2 = dict(q, wl=np.float32(0.5))
+    assert torch.equal(mrirt.render_brats(q2, [g], ext=ext), mrirt.render_brats(q2, [g], ext=ext, skip=True))
+    assert render.skip_map_builds == builds + 2
 
-    def timed(skip):
-        for _ in range(3):
-            mrirt.render_brats(p, [g], out=out, ext=ext, skip=skip)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(10):
-            mrirt.render_brats(p, [g], out=out, ext=ext, skip=skip)
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / 10, out.clone()
-    t_plain, f_plain = timed(False)
-    t_skip, f_skip = timed(True)
-    assert torch.equal(f_plain, f_skip)
-    print(f"\n256^3 blob in air, 512^2 x 384 steps, VG shaded strict: plain {t_plain:.3f} ms, skipping {t_skip:.3f} ms")
-    assert t_skip < 0.95 * t_plain      # measured 0.75; loose on purpose (a timing on a shared box)
+
+@pytest.mark.parametrize("layout", ["vg", "vga"])
+@pytest.mark.parametrize("channels", [2, 4])
+def test_skip_with_several_shaded_modalities_keeps_the_rolling_kernel(layout, channels):
+    """VG / VGA with 2-4 modalities has no skipping kernel; skip=True must then cost nothing — no pre-pass, the
+    rolling kernel as without it — and of course change no bit."""
+    import torch
+    import mrirt
+    from mrirt import synth, render
+    n, image = 64, 128
+    vols, lab = head_in_air(n, channels=channels)
+    p = synth.brats_scene(n, image, 160, channels=channels, intensity_alpha=6.0)
+    p["wl"], p["ww"] = np.float32(0.45), np.float32(0.7)
+    ext = dict(synth.SHADE_EXT, layout=layout)
+    grids = [mrirt.upload_grid(v, (n, n, n), layout) for v in vols]
+    plain, st0 = mrirt.render_brats(p, grids, ext=ext, stats=True)
+    fast, st1 = mrirt.render_brats(p, grids, ext=ext, stats=True, skip=True)
+    assert torch.equal(plain, fast) and st0 == st1
+    # (the host still allocates a scratch; what must not happen is the pre-pass: the mask words stay as allocated)
+    raw = render._last_skip_mask
+    raw.fill_(0x5a5a5a5a)
+    mrirt.render_brats(p, grids, ext=ext, skip=True)
+    assert int((raw != 0x5a5a5a5a).sum()) == 0, "no SKIP kernel for this configuration: the pre-pass must not run"
 
 
 def test_skip_with_tile_sharding():

@@ -259,3 +259,16 @@ def test_bad_steps_are_refused_on_the_host_not_hung_on_the_gpu():
     sp, eye, U, Vv, W = synth.sdf_scene()
     S = params.sdf_params(dict(sp, maxSteps=np.uint32(1 << 24)), eye, U, Vv, W)
     assert lib.mrirt_render_sdf(C.byref(S), 32, 32, dummy, 32, None) == -5
+
+
+def test_torch_ops_refuse_operands_on_different_devices():
+    """every device tensor of one operator call must live on one GPU (the launch then goes to THAT GPU's
+    current stream).  The check itself needs no GPU: any two distinct torch devices exercise it."""
+    import torch
+    from mrirt import torch_ops
+    a, b = torch.empty(1, device="meta"), torch.empty(1)
+    assert torch_ops._one_device([("x", a), ("y", None), ("z", a)]) == a.device
+    with pytest.raises(ValueError, match="same GPU"):
+        torch_ops._one_device([("gIntensity0", a), ("gLabels", b)])
+    with pytest.raises(ValueError):
+        torch_ops._one_device([("x", None)])
