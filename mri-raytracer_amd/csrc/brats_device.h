@@ -90,6 +90,29 @@ __device__ __forceinline__ void locate(const K1Args& a, const float ro[3], const
 // two lets the pipelined kernel keep a whole step of gathers in flight.
 // ---------------------------------------------------------------------------------------
 template <int LAYOUT, bool SHADE> struct Taps;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// A gather the COMPILER DOES NOT KNOW IS A LOAD (pipelined march kernels, brats_march.hip).  hipcc's own wait insertion
+// de-pipelines the two-stage march: it guards the address arithmetic in front of stage B's gathers — temporaries that
+// share registers with B's load destinations — with s_waitcnt vmcnt(7) .. vmcnt(1), i.e. it waits for stage A's gathers
+// before it ISSUES stage B's, whichever way the loop is written (it rotates it back); seen in the ISA of every
+// pipelined kernel, profiles/r03_pipeline_waits.txt.  Issued as asm, a gather is just "an instruction that defines its
+// destination": no wait is inserted anywhere, and the march places the ONE wait it needs itself (Taps::arrive<N>: the
+// stage's registers are in/out operands of the s_waitcnt, so no use can be scheduled above it).  What keeps this sound:
+// (1) the destination is live from the asm to its uses, so the allocator cannot hand the register to anything else while
+// the load is in flight; (2) nothing may READ it before arrive() — tools/check_async_loads.py scans the built library's
+// disassembly for a read (or a copy / spill) of a gather destination between the gather and its wait and fails the build
+// check if there is one; (3) every other vector-memory operation of these kernels (frame store, counters) comes after the loop.
+__device__ __forceinline__ void async_load_vec4(float4& dst, const void* __restrict__ base, uint32_t elem) {
+    f32x4 t;
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(t) : "v"(elem << 4), "s"(base));
+    dst = __builtin_bit_cast(float4, t);
+}
+__device__ __forceinline__ void async_load_u32(uint32_t& dst, const void* __restrict__ base, uint32_t byteOff) {
+    uint32_t t;
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(t) : "v"(byteOff), "s"(base));
+    dst = t;
+}
 
 template <bool SHADE> struct Taps<2, SHADE> {        // VG: 8 x (v, dx, dy, dz)
     float4 c[8];
@@ -102,6 +125,23 @@ template <bool SHADE> struct Taps<2, SHADE> {        // VG: 8 x (v, dx, dy, dz)
         c[2] = load_vec4<w>(vbuf, o01);        c[3] = load_vec4<w>(vbuf, o11);
         c[4] = load_vec4<w>(vbuf, k.o + k.dz); c[5] = load_vec4<w>(vbuf, o10 + k.dz);
         c[6] = load_vec4<w>(vbuf, o01 + k.dz); c[7] = load_vec4<w>(vbuf, o11 + k.dz);
+    }
+    // the same eight gathers as inline asm (issue_async) and the wait that retires them (arrive): see async_load_vec4
+    __device__ __forceinline__ void issue_async(const void* __restrict__ vbuf, const CellOffsets& k) {
+        const uint32_t o10 = k.o + k.dx, o01 = k.o + k.dy, o11 = o10 + k.dy;
+        async_load_vec4(c[0], vbuf, k.o);        async_load_vec4(c[1], vbuf, o10);
+        async_load_vec4(c[2], vbuf, o01);        async_load_vec4(c[3], vbuf, o11);
+        async_load_vec4(c[4], vbuf, k.o + k.dz); async_load_vec4(c[5], vbuf, o10 + k.dz);
+        async_load_vec4(c[6], vbuf, o01 + k.dz); async_load_vec4(c[7], vbuf, o11 + k.dz);
+    }
+    template <int YOUNGER>
+    __device__ __forceinline__ void arrive() {
+        f32x4 t[8];                                          // plain vector types (HIP's float4 class is a memory operand to asm); renames
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t[i] = __builtin_bit_cast(f32x4, c[i]);
+        asm volatile("s_waitcnt vmcnt(%8)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]) : "n"(YOUNGER));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) c[i] = __builtin_bit_cast(float4, t[i]);
     }
     template <bool STRICT>
     __device__ __forceinline__ void eval(const Cell& s, float& v, float g[3]) const {
@@ -123,6 +163,7 @@ template <bool SHADE> struct Taps<2, SHADE> {        // VG: 8 x (v, dx, dy, dz)
 };
 
 template <bool SHADE> struct Taps<4, SHADE> : Taps<2, SHADE> {   // VGA: VG voxels, axis-flat bricks, copy chosen per wave
+    using Taps<2, SHADE>::issue_async;
     template <bool WIDE>
     __device__ __forceinline__ void issue(const void* __restrict__ vbuf, const FlatAxis& f, const Cell& s) {
         const CellOffsets k = flat_cell(f, s.ix, s.iy, s.iz);
@@ -176,6 +217,10 @@ template <> struct Taps<3, false> {                  // QUAD: the z and z+1 xy-q
         const CellOffsets k = vec4_cell(gd, s.ix, s.iy, s.iz);
         q0 = load_vec4<WIDE>(vbuf, k.o);
         q1 = load_vec4<WIDE>(vbuf, k.o + k.dz);
+    }
+    __device__ __forceinline__ void issue_async(const void* __restrict__ vbuf, const CellOffsets& k) {
+        async_load_vec4(q0, vbuf, k.o);
+        async_load_vec4(q1, vbuf, k.o + k.dz);
     }
     template <bool STRICT>
     __device__ __forceinline__ void eval(const Cell& s, float& v, float*) const {
@@ -246,18 +291,38 @@ struct RayState { float C0, C1, C2, T; uint32_t nLive, nShaded; };
 
 // the two nearest-label gathers of a sample (issued with the intensity gathers, consumed in composite)
 struct Labels { uint32_t seg, pred; };
-__device__ __forceinline__ void fetch_labels(const K1Args& a, const Cell& s, Labels& l, int64_t streamRow = 0) {
+__device__ __forceinline__ void fetch_labels(const K1Args& a, const Cell& s, Labels& l) {
     l.seg = a.showSeg != 0 ? sample_label(a.labels, a.lab, s.q, a.hiLab) : 0u;      // :144
+    l.pred = a.showPred != 0 ? sample_label(a.preds, a.lab, s.q, a.hiLab) : 0u;    // :155
+}
+// ... and with the prediction label taken from C5's class stream (one class per sample of the ray; generic kernel only)
+__device__ __forceinline__ void fetch_labels_stream(const K1Args& a, const Cell& s, Labels& l, int64_t streamRow) {
+    l.seg = a.showSeg != 0 ? sample_label(a.labels, a.lab, s.q, a.hiLab) : 0u;
     if (a.showPred == 0) l.pred = 0u;
-    else if (a.classStream != nullptr) l.pred = (uint32_t)(uint16_t)a.classStream[streamRow];   // C5
-    else l.pred = sample_label(a.preds, a.lab, s.q, a.hiLab);                       // :155
+    else if (a.classStream != nullptr) l.pred = (uint32_t)(uint16_t)a.classStream[streamRow];
+    else l.pred = sample_label(a.preds, a.lab, s.q, a.hiLab);
 }
 
 // GAMMA1: gamma == 1 (the viewer's constant, brats_viewer.py:422), where pow(val, 1) == val exactly;
 // compiling the fp64 pow out of the hot kernels frees the registers its temporaries would claim.
+// The overlays' per-label constants (lutColorAlpha[l].rgb and the two opacities) are indexed by a per-lane label.  Straight
+// from the kernel arguments that is a VECTOR-memory load from the kernarg segment inside a divergent branch — and a load
+// the compiler cannot count past: every s_waitcnt vmcnt of the march then drops to 0 and the software pipeline (the next
+// step's gathers in flight under this step's compositing) is gone (seen in the ISA of the config-2 kernel; VERDICT r2 #5 had
+// it "latency-bound").  So every kernel that draws overlays copies the sixteen rows into LDS once per workgroup
+// (stage_lut) and reads them with ds_read_b128: lgkmcnt, not vmcnt.  Rows 0-7: (rgb, segAlpha), rows 8-15: (rgb, predAlpha).
+__device__ __forceinline__ const float4* stage_lut(const K1Args& a, float4* lutS) {
+    if (threadIdx.x < 16u) {
+        const uint32_t l = threadIdx.x & 7u;
+        lutS[threadIdx.x] = make_float4(a.lut[l][0], a.lut[l][1], a.lut[l][2], threadIdx.x < 8u ? a.segAlpha[l] : a.predAlpha[l]);
+    }
+    __syncthreads();
+    return lutS;
+}
+
 template <bool STRICT, bool SHADE, bool GAMMA1 = false, bool LABELS = true>
 __device__ __forceinline__ void composite(const K1Args& a, const float rd[3], const Labels& lb, float v, const float g[3],
-                                          RayState& r) {
+                                          RayState& r, const float4* lutS = nullptr) {
     using Mm = M<STRICT>;
     // wSum (brats_rt.slang:123-130) is the same for every sample: summed on the host
     if (a.wsum.d > 0.0f && a.wsum.d != 1.0f) v = Mm::divu(v, a.wsum);      // x / 1 == x: skip the three instructions
@@ -298,18 +363,20 @@ __device__ __forceinline__ void composite(const K1Args& a, const float rd[3], co
     if (LABELS && a.showSeg != 0) {                                  // :143-151
         const uint32_t l = lb.seg;
         if (l > 0 && l < 8) {
-            const float alpha = a.segAlpha[l];                           // 1 - exp(-lut[l].w * dt): seven values per launch, host-made
+            const float4 e = lutS[l];                                    // (rgb, 1 - exp(-lut[l].w * dt)): host-made, LDS-resident
+            const float alpha = e.w;
             const float at = alpha * r.T;
-            r.C0 += at * a.lut[l][0]; r.C1 += at * a.lut[l][1]; r.C2 += at * a.lut[l][2];
+            r.C0 += at * e.x; r.C1 += at * e.y; r.C2 += at * e.z;
             r.T *= (1.0f - alpha);
         }
     }
     if (LABELS && a.showPred != 0) {                                 // :154-162
         const uint32_t l = lb.pred;
         if (l > 0 && l < 8) {
-            const float alpha = a.predAlpha[l];                          // 1 - exp(-lut[l].w * dt * 1.5)
+            const float4 e = lutS[8u + l];                               // (rgb, 1 - exp(-lut[l].w * dt * 1.5))
+            const float alpha = e.w;
             const float at = alpha * r.T;
-            r.C0 += at * a.lut[l][0]; r.C1 += at * a.lut[l][1]; r.C2 += at * a.lut[l][2];
+            r.C0 += at * e.x; r.C1 += at * e.y; r.C2 += at * e.z;
             r.T *= (1.0f - alpha);
         }
     }

@@ -34,6 +34,8 @@ namespace mrirt {
 template <bool STRICT, int LAYOUT, bool SHADE>
 __global__ __launch_bounds__(256) void brats_march_kernel(const K1Args a) {
     using Mm = M<STRICT>;
+    __shared__ float4 lutShared[16];
+    const float4* lutS = stage_lut(a, lutShared);
     uint32_t px, py;
     int64_t oidx;
     const int kind = map_pixel(a.map, px, py, oidx);
@@ -65,8 +67,8 @@ __global__ __launch_bounds__(256) void brats_march_kernel(const K1Args a) {
                 }
             }
             Labels lb;
-            fetch_labels(a, s, lb, streamBase + r.nLive);       // nLive == index of this step along the ray
-            composite<STRICT, SHADE>(a, rd, lb, v, g, r);
+            fetch_labels_stream(a, s, lb, streamBase + r.nLive); // nLive == index of this step along the ray
+            composite<STRICT, SHADE>(a, rd, lb, v, g, r, lutS);
             t += a.stepSize;
         }
     }
@@ -150,9 +152,59 @@ struct Stage {
     uint32_t dist;                   // SKIP: the map byte of the sample's macro cell (0 = fetch and composite)
     bool empty;
     __device__ __forceinline__ void classify(uint32_t d) { dist = d; empty = SKIP && d != 0u; }
-    // streamRow / streamValid: C5's class stream (one class per sample of the ray); the fetch of step k+1 is
-    // speculative, so it is made only when that sample exists (t_next < t1)
-    __device__ __forceinline__ void issue(const K1Args& a, const WaveGrid<LAYOUT>& wg, int64_t streamRow = 0, bool streamValid = true) {
+    // (The class stream of the whole-ray C5 form is NOT read here: its per-lane "does that sample exist" test put the label
+    // loads into a divergent branch, and a load the compiler cannot count past turns every vmcnt of the loop into 0 — for the
+    // plain kernels too.  mrirt_render_brats_stream takes the generic kernel.)
+    // ---- the asynchronous form (plain pipelined kernels: !SKIP): gathers the compiler does not count, one explicit wait ----
+    static constexpr int kTapLoads = NCH * (LAYOUT == 3 ? 2 : 8);
+    static constexpr int kLoads = kTapLoads + (LABELS ? 2 : 0);          // vector-memory instructions issue_async() emits
+    __device__ __forceinline__ void issue_async(const K1Args& a, const WaveGrid<LAYOUT>& wg) {
+        CellOffsets k;
+        if constexpr (LAYOUT == 4) k = flat_cell(wg.f, s.ix, s.iy, s.iz);
+        else k = vec4_cell(*wg.g, s.ix, s.iy, s.iz);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) taps[c].issue_async(wg.base(a.vol[a.chan[c]]), k);
+        if constexpr (LABELS) {
+            // both label gathers are ALWAYS issued (a hidden overlay reads word 0 of the first modality and is masked in
+            // arrive()): the count the wait rests on must not depend on the overlays
+            const uint32_t ix = (uint32_t)roundf(clampf(s.q[0], 0.0f, a.hiLab[0]));
+            const uint32_t iy = (uint32_t)roundf(clampf(s.q[1], 0.0f, a.hiLab[1]));
+            const uint32_t iz = (uint32_t)roundf(clampf(s.q[2], 0.0f, a.hiLab[2]));
+            const uint32_t off = a.lab.off(ix, iy, iz) << 2;               // sampleLabel, brats_rt.slang:78-83 (label grids < 4 GiB: launch())
+            const void* dummy = a.vol[a.chan[0]];
+            async_load_u32(lb.seg, a.showSeg != 0 ? (const void*)a.labels : dummy, a.showSeg != 0 ? off : 0u);
+            async_load_u32(lb.pred, a.showPred != 0 ? (const void*)a.preds : dummy, a.showPred != 0 ? off : 0u);
+        }
+    }
+    // every load of this stage has landed; YOUNGER = vector-memory instructions issued after them (the other stage's)
+    template <int YOUNGER>
+    __device__ __forceinline__ void arrive(const K1Args& a) {
+        if constexpr (LAYOUT == 3) {
+            // exactly this stage's registers as in/out operands (an operand listed twice would be COPIED into a second
+            // register in front of the asm: a read of a gather destination that has not landed)
+            f32x4 q[2 * NCH];
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) { q[2 * c] = __builtin_bit_cast(f32x4, taps[c].q0); q[2 * c + 1] = __builtin_bit_cast(f32x4, taps[c].q1); }
+            if constexpr (NCH == 1) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(q[0]), "+v"(q[1]) : "n"(YOUNGER));
+            if constexpr (NCH == 2) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2 % (2 * NCH)]), "+v"(q[3 % (2 * NCH)]) : "n"(YOUNGER));
+            if constexpr (NCH == 3) asm volatile("s_waitcnt vmcnt(%6)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2 % (2 * NCH)]), "+v"(q[3 % (2 * NCH)]),
+                                                 "+v"(q[4 % (2 * NCH)]), "+v"(q[5 % (2 * NCH)]) : "n"(YOUNGER));
+            if constexpr (NCH == 4) asm volatile("s_waitcnt vmcnt(%8)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2 % (2 * NCH)]), "+v"(q[3 % (2 * NCH)]),
+                                                 "+v"(q[4 % (2 * NCH)]), "+v"(q[5 % (2 * NCH)]), "+v"(q[6 % (2 * NCH)]), "+v"(q[7 % (2 * NCH)]) : "n"(YOUNGER));
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) { taps[c].q0 = __builtin_bit_cast(float4, q[2 * c]); taps[c].q1 = __builtin_bit_cast(float4, q[2 * c + 1]); }
+        } else {
+            static_assert(LAYOUT == 3 || NCH == 1, "VG / VGA stages hold one modality");
+            taps[0].template arrive<YOUNGER>();
+        }
+        if constexpr (LABELS) {
+            uint32_t ls = lb.seg, lp = lb.pred;
+            asm volatile("" : "+v"(ls), "+v"(lp));                          // (the label words arrived with the taps: same wait)
+            lb.seg = a.showSeg != 0 ? ls : 0u;
+            lb.pred = a.showPred != 0 ? lp : 0u;
+        }
+    }
+    __device__ __forceinline__ void issue(const K1Args& a, const WaveGrid<LAYOUT>& wg) {
         // SKIP: a sample that fetches nothing still ISSUES its gathers, all at cell (0,0,0) — loads inside a branch would
         // make every later s_waitcnt vmcnt conservative (the counter retires in order; a load that may or may not have
         // been issued cannot be counted past), i.e. vmcnt(0) everywhere and no pipelining at all: measured 1.8x on a
@@ -161,13 +213,10 @@ struct Stage {
         if (SKIP && empty) { c0.ix = 0u; c0.iy = 0u; c0.iz = 0u; }
 #pragma unroll
         for (int c = 0; c < NCH; ++c) taps[c].template issue<false>(wg.base(a.vol[a.chan[c]]), wg.dims(), c0);   // grid (copy) < 4 GiB (launch())
-        if constexpr (LABELS) {
-            if (a.classStream != nullptr && !streamValid) { lb.seg = a.showSeg != 0 ? sample_label(a.labels, a.lab, s.q, a.hiLab) : 0u; lb.pred = 0u; }
-            else fetch_labels(a, s, lb, streamRow);
-        }
+        if constexpr (LABELS) fetch_labels(a, s, lb);
     }
     template <bool STRICT, bool GAMMA1>
-    __device__ __forceinline__ void consume(const K1Args& a, const float rd[3], RayState& r) const {
+    __device__ __forceinline__ void consume(const K1Args& a, const float rd[3], RayState& r, const float4* lutS = nullptr) const {
         using Mm = M<STRICT>;
         if (SKIP && empty) {
             ++r.nLive;
@@ -194,7 +243,7 @@ struct Stage {
             }
         }
         if constexpr (LABELS) {
-            composite<STRICT, SHADE, GAMMA1>(a, rd, lb, v, g, r);
+            composite<STRICT, SHADE, GAMMA1>(a, rd, lb, v, g, r, lutS);
         } else {
             const Labels none = { 0u, 0u };
             composite<STRICT, SHADE, GAMMA1, false>(a, rd, none, v, g, r);
@@ -213,7 +262,7 @@ struct Stage {
 // The class stream of C5 is not supported here (the launchers never combine the two).
 template <bool STRICT, int LAYOUT, bool SHADE, int NCH, bool GAMMA1, bool LABELS>
 __device__ __forceinline__ void march_skip(const K1Args& a, const WaveGrid<LAYOUT>& wg, const float ro[3], const float rd[3],
-                                           float t0, float t1, bool marches, RayState& r) {
+                                           float t0, float t1, bool marches, RayState& r, const float4* lutS) {
     bool alive = marches;
     if (__ballot(alive) == 0) return;
     float t = t0;
@@ -256,7 +305,7 @@ __device__ __forceinline__ void march_skip(const K1Args& a, const WaveGrid<LAYOU
             B.classify(alive ? dB : 1u);
             leave = __ballot(alive && dB == 0u) == 0;                // the packet's next sample is flagged throughout
             B.issue(a, wg);                                          // (issued regardless: see Stage::issue)
-            if (alive) A.template consume<STRICT, GAMMA1>(a, rd, r);
+            if (alive) A.template consume<STRICT, GAMMA1>(a, rd, r, lutS);
             t = alive ? tn : t;
             alive = alive && t < t1 && r.T > a.ert;
             if (leave || __ballot(alive) == 0) { A.s = B.s; dA = dB; break; }
@@ -266,7 +315,7 @@ __device__ __forceinline__ void march_skip(const K1Args& a, const WaveGrid<LAYOU
             A.classify(alive ? dA : 1u);
             leave = __ballot(alive && dA == 0u) == 0;
             A.issue(a, wg);
-            if (alive) B.template consume<STRICT, GAMMA1>(a, rd, r);
+            if (alive) B.template consume<STRICT, GAMMA1>(a, rd, r, lutS);
             t = alive ? tn : t;
             alive = alive && t < t1 && r.T > a.ert;
             if (leave || __ballot(alive) == 0) break;                // A.s / dA already describe the sample at t
@@ -277,6 +326,9 @@ __device__ __forceinline__ void march_skip(const K1Args& a, const WaveGrid<LAYOU
 
 template <bool STRICT, int LAYOUT, bool SHADE, int NCH, bool GAMMA1, bool LABELS, bool SKIP>
 __global__ __launch_bounds__(256, (LABELS || SKIP) ? 3 : 4) void brats_march_pipe_kernel(const K1Args a) {
+    __shared__ float4 lutShared[LABELS ? 16 : 1];
+    const float4* lutS = nullptr;
+    if constexpr (LABELS) lutS = stage_lut(a, lutShared);
     uint32_t px, py;
     int64_t oidx;
     const int kind = map_pixel(a.map, px, py, oidx);
@@ -287,32 +339,49 @@ __global__ __launch_bounds__(256, (LABELS || SKIP) ? 3 : 4) void brats_march_pip
     if constexpr (LAYOUT == 4) wg.f = a.vga.ax[vga_pick_axis(a, ro, rd, marches)];      // every lane votes: outside the branch
     else wg.g = &a.grid;
     if constexpr (SKIP) {
-        march_skip<STRICT, LAYOUT, SHADE, NCH, GAMMA1, LABELS>(a, wg, ro, rd, t0, t1, marches, r);
+        march_skip<STRICT, LAYOUT, SHADE, NCH, GAMMA1, LABELS>(a, wg, ro, rd, t0, t1, marches, r, lutS);
     } else if (marches) {
-        float t = t0;
+        // Two stages, each consumed and then re-issued TWO steps ahead:   consume A(k); issue A(k+2); consume B(k+1); issue B(k+3).
+        // (Round 2 had "issue B(k+1); consume A(k)": hipcc then guarded the address arithmetic that precedes B's gathers —
+        // temporaries in registers it also uses as B's load destinations — with s_waitcnt vmcnt(7) .. vmcnt(1) at the top of
+        // every trip, i.e. it waited for A's gathers BEFORE issuing B's, and half of the overlap was gone: seen in the ISA of
+        // every pipelined kernel.  In this order every wait sits in front of the blend that needs it and nothing else.)
+        // t runs exactly as in the shader: t_{k+1} = t_k + stepSize (brats_rt.slang:164), one running fp32 sum.
         Stage<LAYOUT, SHADE, NCH, LABELS, SKIP> A, B;
-        int64_t row = 0;                                             // C5: next row of this ray in the class stream
-        if constexpr (LABELS) { if (a.classStream != nullptr) row = a.rayOffsets[(int64_t)py * a.map.width + px]; }
-        locate<STRICT>(a, ro, rd, t, A.s);
-        A.classify(0u);
-        A.issue(a, wg, row++, true);
+        constexpr int kN = Stage<LAYOUT, SHADE, NCH, LABELS, SKIP>::kLoads;
+        // ONE static issue site and ONE wait per stage: a second site (a prologue that primes the stages) makes the stage's
+        // registers a phi at the loop header, and the copies the allocator resolves phis with would read gather destinations
+        // that are still in flight (tools/check_async_loads.py found exactly that).  So the pipeline fills inside the loop:
+        // the first trip skips both consumes (n counts the steps issued so far).
+        float tI = t0;                                           // time of the next sample to ISSUE (the running sum)
+        float tA = t0, tB = t0;                                  // time of the sample each stage holds
+        uint32_t n = 0;
         while (true) {
-            // invariant: stage A holds the sample at t, and (t < t1 && T > ert) holds
-            float tn = t + a.stepSize;
-            locate<STRICT>(a, ro, rd, tn, B.s);
-            B.classify(0u);
-            B.issue(a, wg, row++, tn < t1);                       // speculative next step
-            A.template consume<STRICT, GAMMA1>(a, rd, r);
-            t = tn;
-            if (!(t < t1 && r.T > a.ert)) break;
-            tn = t + a.stepSize;
-            locate<STRICT>(a, ro, rd, tn, A.s);
+            if (n != 0u) {
+                A.template arrive<kN>(a);                        // B's kN loads may still be in flight
+                A.template consume<STRICT, GAMMA1>(a, rd, r, lutS);
+                if (!(tB < t1 && r.T > a.ert)) break;            // brats_rt.slang:117 for the next sample (held by B)
+            }
+            tA = tI;
+            locate<STRICT>(a, ro, rd, tA, A.s);                  // beyond the ray's end the sample is speculative: clamped addresses
             A.classify(0u);
-            A.issue(a, wg, row++, tn < t1);
-            B.template consume<STRICT, GAMMA1>(a, rd, r);
-            t = tn;
-            if (!(t < t1 && r.T > a.ert)) break;
+            A.issue_async(a, wg);
+            tI += a.stepSize;
+            if (n != 0u) {
+                B.template arrive<kN>(a);
+                B.template consume<STRICT, GAMMA1>(a, rd, r, lutS);
+                if (!(tA < t1 && r.T > a.ert)) break;
+            }
+            tB = tI;
+            locate<STRICT>(a, ro, rd, tB, B.s);
+            B.classify(0u);
+            B.issue_async(a, wg);
+            tI += a.stepSize;
+            n = 1u;
         }
+        // the speculative gathers of the stage that was not consumed are still in flight: their destinations must stay
+        // untouched until they land (the registers are dead to the compiler from here on)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     finish(a, kind, oidx, r);
 }
@@ -328,6 +397,9 @@ __global__ __launch_bounds__(256, (LABELS || SKIP) ? 3 : 4) void brats_march_pip
 template <bool STRICT, int LAYOUT, bool SHADE, int NCH, bool GAMMA1, bool LABELS>
 __global__ __launch_bounds__(256, 2) void brats_march_roll_kernel(const K1Args a) {
     using Mm = M<STRICT>;
+    __shared__ float4 lutShared[LABELS ? 16 : 1];
+    const float4* lutS = nullptr;
+    if constexpr (LABELS) lutS = stage_lut(a, lutShared);
     uint32_t px, py;
     int64_t oidx;
     const int kind = map_pixel(a.map, px, py, oidx);
@@ -342,11 +414,9 @@ __global__ __launch_bounds__(256, 2) void brats_march_roll_kernel(const K1Args a
         Taps<LAYOUT, SHADE> tp[2];                                  // pair k lives in tp[k & 1]
         Cell cs[2];                                                 // cell of the step a pair belongs to: step parity
         Labels lb[2];
-        int64_t row = 0;
-        if constexpr (LABELS) { if (a.classStream != nullptr) row = a.rayOffsets[(int64_t)py * a.map.width + px]; }
         locate<STRICT>(a, ro, rd, t, cs[0]);
         tp[0].template issue<false>(wg.base(a.vol[a.chan[0]]), wg.dims(), cs[0]);
-        if constexpr (LABELS) fetch_labels(a, cs[0], lb[0], row++);
+        if constexpr (LABELS) fetch_labels(a, cs[0], lb[0]);
         bool done = false;
         while (!done) {
             // two steps per trip: 2 NCH pairs, so the buffer parity of a pair is a compile-time value
@@ -364,10 +434,7 @@ __global__ __launch_bounds__(256, 2) void brats_march_roll_kernel(const K1Args a
                     } else {
                         locate<STRICT>(a, ro, rd, tn, cs[sp ^ 1]);  // the next step's cell (the ray may end here: harmless)
                         tp[(k + 1) & 1].template issue<false>(wg.base(a.vol[a.chan[0]]), wg.dims(), cs[sp ^ 1]);
-                        if constexpr (LABELS) {
-                            if (a.classStream != nullptr && !(tn < t1)) { lb[sp ^ 1].seg = a.showSeg != 0 ? sample_label(a.labels, a.lab, cs[sp ^ 1].q, a.hiLab) : 0u; lb[sp ^ 1].pred = 0u; }
-                            else fetch_labels(a, cs[sp ^ 1], lb[sp ^ 1], row++);
-                        }
+                        if constexpr (LABELS) fetch_labels(a, cs[sp ^ 1], lb[sp ^ 1]);
                     }
                     // consume pair k: brats_rt.slang:123-130, ascending modality order
                     float sv, gm[3];
@@ -382,7 +449,7 @@ __global__ __launch_bounds__(256, 2) void brats_march_roll_kernel(const K1Args a
                     // (8 x 32 registers) and spills
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if constexpr (LABELS) composite<STRICT, SHADE, GAMMA1>(a, rd, lb[sp], v, g, r);
+                if constexpr (LABELS) composite<STRICT, SHADE, GAMMA1>(a, rd, lb[sp], v, g, r, lutS);
                 else { const Labels none = { 0u, 0u }; composite<STRICT, SHADE, GAMMA1, false>(a, rd, none, v, g, r); }
                 t = tn;
                 done = !(t < t1 && r.T > a.ert);
@@ -430,7 +497,10 @@ static int launch_pipe(const K1Args& a, hipStream_t s) {
 }
 
 template <bool STRICT, int LAYOUT, bool SHADE>
-static int launch(const K1Args& a, bool pipe, hipStream_t s) {
+static int launch(const K1Args& a, bool pipeAsked, hipStream_t s) {
+    // the pipelined kernels address label words with 32-bit byte offsets (Stage::issue_async)
+    const uint64_t labelElems = (uint64_t)((a.grid.X + 3u) & ~3u) * ((a.grid.Y + 3u) & ~3u) * ((a.grid.Z + 1u) & ~1u);
+    const bool pipe = pipeAsked && !((a.showSeg != 0 || a.showPred != 0) && labelElems >= (1ull << 30));
     if constexpr (LAYOUT == 2) {                      // VG: 8 float4 per modality per stage -> one modality; more: rolling pairs
         if (pipe && a.nch == 1 && !a.grid.wide) return launch_pipe<STRICT, 2, SHADE, 1>(a, s);
         if (pipe && !a.grid.wide && a.skipDist == nullptr && a.showSeg == 0 && a.showPred == 0) {   // (with overlays the generic kernel measured faster)
@@ -684,6 +754,8 @@ __global__ __launch_bounds__(256) void c5_composite_kernel(const K1Args a, C5Ray
                                                            const float* __restrict__ mix, const uint32_t* __restrict__ seg,
                                                            uint2* __restrict__ rowOwner, uint32_t* __restrict__ nextCounter,
                                                            uint32_t chunk) {
+    __shared__ float4 lutShared[16];
+    const float4* lutS = stage_lut(a, lutShared);
     uint32_t px, py;
     int64_t oidx;
     const int kind = map_pixel(a.map, px, py, oidx);
@@ -725,7 +797,7 @@ __global__ __launch_bounds__(256) void c5_composite_kernel(const K1Args a, C5Ray
         alive = alive && st.cnt > k && r.T > a.ert;
         if (__ballot(alive) == 0) break;                 // every ray of the wave is done with this pass
         if (alive) {
-            composite<STRICT, SHADE>(a, rd, cur.lb, cur.v, cur.g, r);
+            composite<STRICT, SHADE>(a, rd, cur.lb, cur.v, cur.g, r, lutS);
             t += a.stepSize;
         }
         cur = nxt;
@@ -795,7 +867,10 @@ static int prepare(const MrirtBratsParams* p, const MrirtRenderExt* ext, const v
     const uint32_t bandAsked = bandSel == 0 ? (bigBlocks ? 16u : 8u) : bandSel == 1 ? 16u : bandSel == 2 ? 32u : 64u;
     const uint32_t bandPx = (variant & 8u) ? 0u : bandAsked;
     int rc = fill_pixel_map(a.map, p->imageSize[0], p->imageSize[1], pitch_px, ext,
-                            bigBlocks ? 16u : 8u, (variant & 1u) ? 0u : 1u, bandPx);
+                            bigBlocks ? 16u : 8u, (variant & 1u) ? 0u : 1u, bandPx,
+                            // the per-band shift of the workgroup order (PixelMap::bandShift): config 2 0.591 -> 0.457 ms; on the
+                            // 16-px workgroups of VGA grids it measured 1.3 % slower (C3), so those keep straight bands.  Bit 9 flips it.
+                            ((variant & 512u) == 0u) != bigBlocks);
     if (rc != MRIRT_OK) return rc;
     fill_grid_dims(a.grid, p->dims, layout == MRIRT_LAYOUT_VGA ? (uint32_t)MRIRT_LAYOUT_VG : layout);
     fill_vga_dims(a.vga, p->dims);
@@ -926,6 +1001,7 @@ using namespace mrirt;
 //   bit 6: the LDS-staged kernel of brats_slab.hip     bit 7: ... counts its LDS-served samples in stats[1]; the skipping
 //                                                             kernels: the samples they did NOT fetch (flagged or leapt)
 //   bit 8: skipping one step at a time (no leaps); in the slab kernel: count ring misses
+//   bit 9: every band of an XCD starts at x = 0 (no per-band shift of the workgroup order: PixelMap::bandShift)
 extern "C" int mrirt_render_brats_ex(const MrirtBratsParams* p, const MrirtRenderExt* ext,
                                      const void* const vol[4], const void* labels, const void* preds,
                                      void* out_rgba, int64_t pitch_px, uint64_t* stats_dev, void* stream) {
@@ -1035,8 +1111,9 @@ extern "C" int mrirt_render_brats_stream(const MrirtBratsParams* p, const MrirtR
     a.classStream = classes; a.rayOffsets = offsets;
     a.out = out_rgba; a.stats = stats_dev;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    return cfg.math == MRIRT_MATH_STRICT ? launch_layout<true>(a, cfg.layout, cfg.shade, cfg.pipe, s)
-                                         : launch_layout<false>(a, cfg.layout, cfg.shade, cfg.pipe, s);
+    // the generic kernel: the pipelined ones do not read a class stream (Stage::issue)
+    return cfg.math == MRIRT_MATH_STRICT ? launch_layout<true>(a, cfg.layout, cfg.shade, false, s)
+                                         : launch_layout<false>(a, cfg.layout, cfg.shade, false, s);
 }
 
 extern "C" int mrirt_brats_sample_counts(const MrirtBratsParams* p, const MrirtRenderExt* ext, uint32_t* counts, void* stream) {

@@ -74,8 +74,9 @@ __global__ __launch_bounds__(256) void vga_build_kernel(const float* __restrict_
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;      // float4 index inside this copy
     if (e >= total) return;
     const uint32_t in = (uint32_t)(e & 7u);
-    const uint64_t b = e >> 3;
-    const uint32_t bc[3] = { (uint32_t)(b % nb0), (uint32_t)((b / nb0) % nb1), (uint32_t)(b / ((uint64_t)nb0 * nb1)) };
+    const uint64_t b = e >> 3;                                               // line: rows of nb0 lines, slices of nb1 lines (padded pitches)
+    const uint32_t inSlice = (uint32_t)(b % nb1);
+    const uint32_t bc[3] = { inSlice % nb0, inSlice / nb0, (uint32_t)(b / nb1) };   // pad lines decode to voxels outside the grid: zeros
     uint32_t p[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k)                                               // invert o_k(i) = (i >> sh) mul + (i & mask) inner
@@ -243,7 +244,7 @@ extern "C" int mrirt_build_vec4_grid(const float* linear, void* vec4_grid, const
             const uint64_t total = vga_copy_elems(dims, a);
             if (total >= (1ull << 28)) return MRIRT_ERR_DIMS;                      // 32-bit byte offsets inside a copy
             const FlatAxis& f = v.ax[a];
-            const uint32_t nb0 = f.mul[1] / 8, nb1 = f.mul[2] / f.mul[1];
+            const uint32_t nb0 = f.mul[1] / 8, nb1 = f.mul[2] / 8;                  // row pitch, slice pitch (lines)
             hipLaunchKernelGGL(vga_build_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, s, linear,
                                reinterpret_cast<float4*>(static_cast<char*>(vec4_grid) + f.baseBytes), f,
                                dims[0], dims[1], dims[2], nb0, nb1, total);

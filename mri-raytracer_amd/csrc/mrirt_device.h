@@ -297,6 +297,7 @@ struct PixelMap {
     uint32_t laneOrder;                // 0 row-major 8x8 packet, 1 Morton (2x2 pixel quads per 4 lanes)
     uint32_t blockPx;                  // 16: 256-thread workgroups (2x2 packets); 8: one packet per workgroup
     uint32_t bandBlocks;               // whole-frame XCD interleave: workgroups per band (0 = contiguous runs)
+    uint32_t bandShift;                // whole frame: an XCD's j-th band starts bandShift * j workgroups further along x (mod blocksX)
     int64_t  pitch;                    // pixels per output row (whole-frame mode)
 };
 
@@ -313,8 +314,14 @@ __device__ __forceinline__ int map_pixel(const PixelMap& m, uint32_t& px, uint32
         // to the XCDs — XCD x marches bands x, x+8, x+16, ... so the mostly-empty top and bottom of
         // the image are shared out, while each band is still a contiguous slab for one L2
         const uint32_t xcd = b % kXcds, k = b / kXcds;
-        const uint32_t band = (k / m.bandBlocks) * kXcds + xcd;
-        logical = band * m.bandBlocks + k % m.bandBlocks;
+        const uint32_t j = k / m.bandBlocks, band = j * kXcds + xcd;
+        uint32_t p = k % m.bandBlocks;
+        // Inside an XCD the dispatcher deals consecutive workgroups over CUs and SIMDs, so workgroups a whole band apart land
+        // on the same SIMD: without a shift a SIMD marches the SAME image column in every band it gets — all long centre
+        // rays on one SIMD, all short edge rays on its neighbour (config 2: the frame took as long as the centre-column
+        // SIMDs).  Starting each band 3/8 of a row further along spreads every SIMD's packets over the width of the image.
+        if (m.bandShift != 0) { const uint32_t row = p / m.blocksX, x = (p % m.blocksX + j * m.bandShift) % m.blocksX; p = row * m.blocksX + x; }
+        logical = band * m.bandBlocks + p;
     } else {
         logical = (b % kXcds) * m.chunk + b / kXcds;     // one contiguous run per XCD
     }

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/mrirt.h"
@@ -65,7 +66,7 @@ inline void fill_camera(Camera& c, const float eye[3], const float U[3], const f
 // returns MRIRT_OK or an error; grid size = map.chunk * 8 workgroups of 256 threads
 // blockPx: 16 (256-thread workgroups) or 8 (64-thread workgroups); laneOrder: see PixelMap
 inline int fill_pixel_map(PixelMap& m, uint32_t width, uint32_t height, int64_t pitch, const MrirtRenderExt* ext,
-                          uint32_t blockPx = kBlockPx, uint32_t laneOrder = 0, uint32_t bandPx = 0) {
+                          uint32_t blockPx = kBlockPx, uint32_t laneOrder = 0, uint32_t bandPx = 0, bool shiftBands = false) {
     if (width == 0 || height == 0) return MRIRT_ERR_DIMS;
     m.width = width; m.height = height; m.pitch = pitch;
     m.tileSize = ext ? ext->tileSize : 0u;
@@ -88,12 +89,14 @@ inline int fill_pixel_map(PixelMap& m, uint32_t width, uint32_t height, int64_t 
     }
     m.chunk = (m.numBlocks + kXcds - 1) / kXcds;
     m.bandBlocks = 0;
+    m.bandShift = 0;
     if (m.tileSize == 0 && bandPx >= blockPx) {
         // XCD-interleaved bands (see map_pixel): bandPx / blockPx workgroup rows per band
         const uint32_t bandRows = bandPx / blockPx, blocksY = (height + blockPx - 1) / blockPx;
         const uint32_t bands = (blocksY + bandRows - 1) / bandRows;
         m.bandBlocks = m.blocksX * bandRows;
         m.chunk = ((bands + kXcds - 1) / kXcds) * m.bandBlocks;
+        if (shiftBands && m.blocksX >= 8) m.bandShift = (3 * m.blocksX) / 8;
     } else if (m.tileSize != 0 && bandPx >= blockPx && m.tileSize % bandPx == 0 && m.numBlocks != 0) {
         // tile mode: a tile's workgroups are row-major inside the tile, so bandPx-high slabs of each tile are
         // runs of consecutive workgroups; deal THOSE round-robin to the XCDs (a rank's tiles are row-major over
@@ -125,28 +128,49 @@ inline void fill_grid_dims(GridDims& g, const uint32_t dims[3], uint32_t layout)
 }
 
 // VGA: copy `a` has bricks one voxel thick along axis a and 4 x 2 along the other two (in ascending axis order).
-// Returns the float4 elements of copy a (bricks padded to whole lines).
-inline uint64_t vga_copy_elems(const uint32_t dims[3], int a) {
-    uint64_t n = 8;
+// Bricks (128-B lines) are stored x-fastest in rows of rowLines lines and slices of sliceLines lines.  The row and the
+// slice pitch are PADDED off the powers of two that 2^n volumes would give them: with a pitch that is a multiple of the
+// vector L1's set count, every line a wave-level gather touches in the two transverse brick directions falls into the
+// same few cache sets (profiles/r03_c3_sets: TCP_READ_TAGCONFLICT_STALL 20 % and TCP_PENDING_STALL 27 % of the cycles on
+// the 512^3 grid) — and into the same L2 channels.  kVgaRowPhase / kVgaSlicePhase are the pitches' residues modulo 64
+// lines: a 4 x 2 x 2-brick neighbourhood then spreads over 16 different sets.
+constexpr uint32_t kVgaSetLines = 64, kVgaRowPhase = 8, kVgaSlicePhase = 36;
+inline uint32_t vga_pad_to_phase(uint64_t lines, uint32_t phase) {
+    static const bool off = getenv("MRIRT_NO_STRIDE_PAD") != nullptr;      // A/B measurements (set before the first upload)
+    if (off || lines < kVgaSetLines) return (uint32_t)lines;
+    const uint32_t r = (uint32_t)(lines % kVgaSetLines);
+    return (uint32_t)(lines + (phase + kVgaSetLines - r) % kVgaSetLines);
+}
+struct VgaGeometry { uint32_t nb[3], rowLines; uint64_t sliceLines; };
+inline VgaGeometry vga_geometry(const uint32_t dims[3], int a) {
+    VgaGeometry g;
     int k4 = 1;                                         // the first non-flat axis gets the 4, the second the 2
     for (int k = 0; k < 3; ++k) {
-        if (k == a) n *= dims[k];
-        else { n *= k4 ? (dims[k] + 3) / 4 : (dims[k] + 1) / 2; k4 = 0; }
+        if (k == a) g.nb[k] = dims[k];
+        else { g.nb[k] = k4 ? (dims[k] + 3) / 4 : (dims[k] + 1) / 2; k4 = 0; }
     }
-    return n;
+    g.rowLines = vga_pad_to_phase(g.nb[0], kVgaRowPhase);
+    g.sliceLines = vga_pad_to_phase((uint64_t)g.rowLines * g.nb[1], kVgaSlicePhase);
+    return g;
+}
+// Returns the float4 elements of copy a (bricks padded to whole lines, rows and slices to their padded pitches).
+inline uint64_t vga_copy_elems(const uint32_t dims[3], int a) {
+    const VgaGeometry g = vga_geometry(dims, a);
+    return g.sliceLines * g.nb[2] * 8;
 }
 inline void fill_vga_dims(VgaDims& v, const uint32_t dims[3]) {
     uint64_t base = 0;
     for (int a = 0; a < 3; ++a) {
         FlatAxis& f = v.ax[a];
-        uint32_t nb[3], innerStride = 1;
+        const VgaGeometry g = vga_geometry(dims, a);
+        uint32_t innerStride = 1;
         int k4 = 1;
         for (int k = 0; k < 3; ++k) {
-            if (k == a) { f.sh[k] = 0; f.mask[k] = 0; f.inner[k] = 0; nb[k] = dims[k]; }
-            else if (k4) { f.sh[k] = 2; f.mask[k] = 3; f.inner[k] = innerStride; innerStride *= 4; nb[k] = (dims[k] + 3) / 4; k4 = 0; }
-            else { f.sh[k] = 1; f.mask[k] = 1; f.inner[k] = innerStride; innerStride *= 2; nb[k] = (dims[k] + 1) / 2; }
+            if (k == a) { f.sh[k] = 0; f.mask[k] = 0; f.inner[k] = 0; }
+            else if (k4) { f.sh[k] = 2; f.mask[k] = 3; f.inner[k] = innerStride; innerStride *= 4; k4 = 0; }
+            else { f.sh[k] = 1; f.mask[k] = 1; f.inner[k] = innerStride; innerStride *= 2; }
         }
-        f.mul[0] = 8; f.mul[1] = nb[0] * 8; f.mul[2] = nb[0] * nb[1] * 8;       // bricks x-fastest, 8 float4 each
+        f.mul[0] = 8; f.mul[1] = g.rowLines * 8; f.mul[2] = (uint32_t)(g.sliceLines * 8);       // bricks x-fastest, 8 float4 each
         for (int k = 0; k < 3; ++k) f.wrap[k] = f.mul[k] - f.mask[k] * f.inner[k];
         f.pad = 0;
         f.baseBytes = base << 4;

@@ -272,3 +272,16 @@ def test_torch_ops_refuse_operands_on_different_devices():
         torch_ops._one_device([("gIntensity0", a), ("gLabels", b)])
     with pytest.raises(ValueError):
         torch_ops._one_device([("x", None)])
+
+
+def test_inline_asm_gathers_are_not_touched_before_their_wait():
+    """The pipelined march kernels issue their gathers as inline asm, invisible to the compiler's wait insertion (and to its
+    notion of "this register is still being loaded").  tools/check_async_loads.py walks the control-flow graph of every such
+    kernel in the BUILT library and fails if any instruction reads or writes a gather destination that may be in flight."""
+    import pathlib
+    import subprocess
+    import sys
+    root = pathlib.Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, str(root / "tools" / "check_async_loads.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-500:]
+    assert "0 kernels failing" in r.stdout

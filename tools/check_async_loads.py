@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""Build check for the inline-asm gathers of the pipelined march kernels (csrc/brats_device.h: async_load_vec4).
+
+The compiler does not know those instructions are loads, so nothing but the kernels' own structure keeps a gather's
+destination registers untouched between the gather and the s_waitcnt that retires it.  This script disassembles the built
+library and, for every non-skipping brats_march_pipe_kernel, walks the code in layout order with a FIFO of outstanding vector
+loads (retired in order by every `s_waitcnt vmcnt(N)`): any instruction that reads OR writes a register of an outstanding
+load — a use scheduled above the wait, a copy, a spill — is reported and the exit status is 1.  (Layout order stands in for
+control flow: the loop bodies of these kernels are straight-line between their waits, and a violation on any path shows up
+as a violation in the listing.)
+
+    python3 tools/check_async_loads.py [path/to/libmrirt.so]
+"""
+import pathlib
+import re
+import subprocess
+import sys
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+LOAD = re.compile(r"^\s*(global_load_dword(?:x[234])?)\s+(v\[\d+:\d+\]|v\d+)\s*,")
+WAIT = re.compile(r"^\s*s_waitcnt\b(.*)")
+REG = re.compile(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b")
+
+
+def regs(tok):
+    out = set()
+    for m in REG.finditer(tok):
+        if m.group(1) is not None:
+            out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+        else:
+            out.add(int(m.group(3)))
+    return out
+
+
+ADDR = re.compile(r"//\s*([0-9A-Fa-f]+):\s*((?:[0-9A-Fa-f]{8}\s*)+)")
+BRANCH = re.compile(r"^(s_branch|s_cbranch_\w+)\s+(-?\d+)")
+
+
+def parse(lines):
+    """[(line_no, addr, size, instruction text)] of one function"""
+    out = []
+    for no, text in lines:
+        m = ADDR.search(text)
+        ins = text.split("//")[0].strip()
+        if not m or not ins:
+            continue
+        out.append((no, int(m.group(1), 16), 4 * len(m.group(2).split()), ins))
+    return out
+
+
+def merge(a, b):
+    """position-wise union of two pending lists (oldest first), aligned at their NEWEST ends"""
+    n = max(len(a), len(b))
+    pa = (frozenset(),) * (n - len(a)) + tuple(a)
+    pb = (frozenset(),) * (n - len(b)) + tuple(b)
+    return tuple(x | y for x, y in zip(pa, pb))
+
+
+def check(name, lines):
+    """Forward data-flow over the function's control-flow graph.  State = the gathers that may still be in flight, oldest
+    first (their destination registers); `s_waitcnt vmcnt(N)` keeps the newest N; at a join the states are united position
+    by position from the newest end.  Any other instruction touching a register of the state is a violation."""
+    ins = parse(lines)
+    if not ins:
+        return []
+    index = {addr: i for i, (_, addr, _, _) in enumerate(ins)}
+    leaders = {0}
+    succ_of = {}
+    for i, (_, addr, size, text) in enumerate(ins):
+        m = BRANCH.match(text)
+        if m:
+            tgt = index.get(addr + size + 4 * int(m.group(2)))
+            nxt = i + 1 if i + 1 < len(ins) else None
+            succ_of[i] = ([tgt] if tgt is not None else []) + ([nxt] if m.group(1) != "s_branch" and nxt is not None else [])
+            if tgt is not None:
+                leaders.add(tgt)
+            if nxt is not None:
+                leaders.add(nxt)
+        elif text.startswith("s_endpgm"):
+            succ_of[i] = []
+            if i + 1 < len(ins):
+                leaders.add(i + 1)
+    starts = sorted(leaders)
+    block_of = {}
+    blocks = []
+    for bi, st in enumerate(starts):
+        en = starts[bi + 1] if bi + 1 < len(starts) else len(ins)
+        blocks.append((st, en))
+        block_of[st] = bi
+    succs = []
+    for st, en in blocks:
+        last = en - 1
+        if last in succ_of:
+            succs.append([block_of[t] for t in succ_of[last] if t in block_of])
+        else:
+            succs.append([block_of[en]] if en in block_of else [])
+
+    def transfer(bi, state, report):
+        st, en = blocks[bi]
+        pend = list(state)
+        for i in range(st, en):
+            no, _, _, text = ins[i]
+            w = WAIT.match(text)
+            if w:
+                m = re.search(r"vmcnt\((\d+)\)", w.group(1))
+                if m:
+                    pend = pend[len(pend) - int(m.group(1)):] if int(m.group(1)) < len(pend) else pend
+                    if int(m.group(1)) == 0:
+                        pend = []
+                continue
+            l = LOAD.match(text)
+            ops = text.split(None, 1)[1] if " " in text else ""
+            touched = regs(ops)
+            if l:
+                dest = regs(l.group(2))
+                touched = regs(ops.split(",", 1)[1]) if "," in ops else set()       # the address operand; the destination is checked below
+                touched |= dest
+            flying = set().union(*pend) if pend else set()
+            if report is not None and touched & flying:
+                report.append((no, text))
+            if l:
+                pend.append(frozenset(regs(l.group(2))))
+                pend = pend[-64:]
+        return tuple(pend)
+
+    instate = {0: ()}
+    work = [0]
+    rounds = 0
+    while work and rounds < 20000:
+        rounds += 1
+        bi = work.pop()
+        out = transfer(bi, instate[bi], None)
+        for sb in succs[bi]:
+            new = out if sb not in instate else merge(instate[sb], out)
+            if sb not in instate or new != instate[sb]:
+                instate[sb] = new
+                work.append(sb)
+    bad = []
+    for bi in sorted(instate):
+        transfer(bi, instate[bi], bad)
+    return bad
+
+
+LLVM = pathlib.Path("/opt/rocm/lib/llvm/bin")
+MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
+
+
+def device_disassembly(so: pathlib.Path) -> str:
+    """gfx950 disassembly of every code object embedded in the library: the .hip_fatbin section holds one offload bundle per
+    HIP source; each is unbundled and disassembled."""
+    import tempfile
+    out = []
+    with tempfile.TemporaryDirectory() as td:
+        td = pathlib.Path(td)
+        fat = td / "fatbin.bin"
+        subprocess.run([str(LLVM / "llvm-objcopy"), "-O", "binary", "--only-section=.hip_fatbin", str(so), str(fat)], check=True)
+        blob = fat.read_bytes()
+        starts = [m.start() for m in re.finditer(re.escape(MAGIC), blob)]
+        for i, st in enumerate(starts):
+            chunk = td / f"bundle{i}.bin"
+            chunk.write_bytes(blob[st:starts[i + 1] if i + 1 < len(starts) else len(blob)])
+            co = td / f"dev{i}.co"
+            r = subprocess.run([str(LLVM / "clang-offload-bundler"), "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                                f"--input={chunk}", f"--output={co}"], capture_output=True, text=True)
+            if r.returncode != 0 or not co.exists() or co.stat().st_size == 0:
+                continue
+            out.append(subprocess.run([str(LLVM / "llvm-objdump"), "-d", str(co)], capture_output=True, text=True).stdout)
+    return "\n".join(out)
+
+
+def main():
+    so = pathlib.Path(sys.argv[1]) if len(sys.argv) > 1 else ROOT / "mri-raytracer_amd" / "libmrirt.so"
+    text = device_disassembly(so)
+    if "s_endpgm" not in text or "brats_march_pipe_kernel" not in text:
+        print(f"{so}: no device disassembly of brats_march_pipe_kernel found")
+        return 2
+    funcs, cur = {}, None
+    for no, line in enumerate(text.splitlines()):
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+        if m:
+            cur = m.group(1)
+            funcs[cur] = []
+        elif cur is not None:
+            funcs[cur].append((no, line))                 # "\t<insn> operands   // addr: encoding"
+    checked = failures = loads = 0
+    for name, lines in funcs.items():
+        if "brats_march_pipe_kernel" not in name or name.startswith("__"):
+            continue
+        # template arguments ...ELb<SKIP>EE: the skipping kernels use compiler-visible loads
+        m = re.search(r"pipe_kernelILb[01]ELi\d+ELb[01]ELi\d+ELb[01]ELb[01]ELb([01])E", name)
+        if not m or m.group(1) == "1":
+            continue
+        checked += 1
+        loads += sum(1 for _, t in lines if LOAD.match(t.split("//")[0].strip()))
+        bad = check(name, lines)
+        if bad:
+            failures += 1
+            print(f"FAIL {name}: {len(bad)} access(es) to an in-flight gather destination")
+            for no, ins in bad[:6]:
+                print(f"   line {no}: {ins}")
+    print(f"check_async_loads: {checked} kernels, {loads} gathers checked, {failures} kernels failing")
+    return 1 if failures or not checked or not loads else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
