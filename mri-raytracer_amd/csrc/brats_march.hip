@@ -860,7 +860,14 @@ static int prepare(const MrirtBratsParams* p, const MrirtRenderExt* ext, const v
     // Workgroup = one 8 x 8 packet (64 threads: a finished packet's wave slot refills at once) — except on VGA grids, where
     // a 16 x 16 block of four packets measured 3.7 % faster (1.145 -> 1.10 ms at C3: the four waves' lines meet in one L1).
     // Variant bit 1 flips the choice; the LDS-staged kernel (bit 6) is written for one packet per workgroup.
-    const bool bigBlocks = ((variant & 2u) != 0u) != (layout == MRIRT_LAYOUT_VGA && (variant & 64u) == 0u);
+    // ... while the launch has enough of them to go round: an eighth of the config-4 frame (one GPU of eight: 2048 workgroups of
+    // 16 x 16 for 1024 resident ones) ends in a long tail of half-idle CUs — 0.616 ms against 0.500 ms with one-packet
+    // workgroups (tools/tile_share_bench.py, profiles/r03_tile_share.txt); from 4096 upwards the big ones win (0.904 vs 0.918).
+    uint64_t blocks16 = (uint64_t)((p->imageSize[0] + 15u) / 16u) * ((p->imageSize[1] + 15u) / 16u);
+    if (ext && ext->tileSize != 0 && ext->tileWorld != 0)
+        blocks16 = (uint64_t)mrirt_tiles_for_rank(p->imageSize[0], p->imageSize[1], ext->tileSize, ext->tileRank, ext->tileWorld) *
+                   ((ext->tileSize + 15u) / 16u) * ((ext->tileSize + 15u) / 16u);
+    const bool bigBlocks = ((variant & 2u) != 0u) != (layout == MRIRT_LAYOUT_VGA && (variant & 64u) == 0u && blocks16 >= 4096u);
     // XCD-interleaved bands one workgroup row high by default (8-px bands for 8 x 8 workgroups: config 2 0.606 -> 0.580 ms,
     // K1 at 512^3 level; variant bit 3: contiguous run per XCD; bits 4-5: 16 / 8 / 32 / 64 px)
     const uint32_t bandSel = (variant >> 4) & 3u;
