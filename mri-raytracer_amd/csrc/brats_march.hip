@@ -394,8 +394,13 @@ __global__ __launch_bounds__(256, (LABELS || SKIP) ? 3 : 4) void brats_march_pip
 // modality 0 of the next step's cell (speculative, clamped addresses).  Two tap sets whatever NCH; the label
 // fetches travel with modality 0.  Same arithmetic in the same order as the shader's modality loop.
 // ---------------------------------------------------------------------------------------
-template <bool STRICT, int LAYOUT, bool SHADE, int NCH, bool GAMMA1, bool LABELS>
+// SKIP (no overlays): exact empty-space skipping at PACKET granularity — while every live ray of the packet sits in a flagged
+// macro cell nothing is fetched and the packet leaps (the empty run of march_skip, verbatim); otherwise the rolling pipeline
+// runs as usual, flagged samples included (their val <= 0 composites nothing: same bits either way).  Every lane stays in
+// the loops (MapWindow's cross-lane reads need the whole wave); finished rays ride along as !alive.
+template <bool STRICT, int LAYOUT, bool SHADE, int NCH, bool GAMMA1, bool LABELS, bool SKIP = false>
 __global__ __launch_bounds__(256, 2) void brats_march_roll_kernel(const K1Args a) {
+    static_assert(!(SKIP && LABELS), "the skipping rolling kernel draws no overlays");
     using Mm = M<STRICT>;
     __shared__ float4 lutShared[LABELS ? 16 : 1];
     const float4* lutS = nullptr;
@@ -409,7 +414,79 @@ __global__ __launch_bounds__(256, 2) void brats_march_roll_kernel(const K1Args a
     WaveGrid<LAYOUT> wg;
     if constexpr (LAYOUT == 4) wg.f = a.vga.ax[vga_pick_axis(a, ro, rd, marches)];
     else wg.g = &a.grid;
-    if (marches) {
+    if constexpr (SKIP) {
+        bool alive = marches;
+        if (__ballot(alive) != 0) {
+            float t = t0;
+            MapWindow win;
+            win.reset();
+            const float stepsPerVoxel = __builtin_amdgcn_rcpf(fmaxf(fmaxf(fabsf(rd[0] * a.vox[0].r), fabsf(rd[1] * a.vox[1].r)),
+                                                                    fabsf(rd[2] * a.vox[2].r)) * a.stepSize);
+            Taps<LAYOUT, SHADE> tp[2];
+            Cell cs[2], c0;
+            locate<STRICT>(a, ro, rd, t, c0);
+            uint32_t d0 = win.lookup(a, c0, rd, alive);
+            while (true) {
+                // invariant: c0 / d0 describe the sample at t; for live rays (t < t1 && T > ert) holds
+                if (__ballot(alive && d0 == 0u) == 0) {                  // every live ray's sample is flagged: the empty run of march_skip
+                    uint32_t n = 1u;
+                    if (a.leap != 0u) {
+                        const uint32_t nl = !alive ? 255u : d0 >= 2u ? min((uint32_t)((float)(8u * (d0 - 1u) - 1u) * stepsPerVoxel), 254u) + 1u : 1u;
+                        n = wave_min8(nl);
+                    }
+                    for (uint32_t i = 0; i < n; ++i) {
+                        const bool go = alive && t < t1;
+                        r.nLive += go ? 1u : 0u;
+                        if (a.debugFlags & 1u) r.nShaded += go ? 1u : 0u;      // (diagnostic: samples not fetched, as Stage::consume)
+                        t = go ? t + a.stepSize : t;
+                    }
+                    alive = alive && t < t1;
+                    if (__ballot(alive) == 0) break;
+                    locate<STRICT>(a, ro, rd, t, c0);
+                    d0 = win.lookup(a, c0, rd, alive);
+                    continue;
+                }
+                // dense run: the rolling pipeline from the sample at t, left when the whole packet's next sample is flagged
+                cs[0] = c0;
+                tp[0].template issue<false>(wg.base(a.vol[a.chan[0]]), wg.dims(), cs[0]);
+                bool out = false;
+                while (!out) {
+#pragma unroll
+                    for (int sp = 0; sp < 2; ++sp) {
+                        if (out) break;
+                        float v = 0.0f, g[3] = { 0.0f, 0.0f, 0.0f };
+                        const float tn = t + a.stepSize;
+                        uint32_t dN = 0u;
+#pragma unroll
+                        for (int c = 0; c < NCH; ++c) {
+                            const int k = sp * NCH + c;
+                            if (c + 1 < NCH) {
+                                tp[(k + 1) & 1].template issue<false>(wg.base(a.vol[a.chan[c + 1]]), wg.dims(), cs[sp]);
+                            } else {
+                                locate<STRICT>(a, ro, rd, tn, cs[sp ^ 1]);
+                                dN = win.lookup(a, cs[sp ^ 1], rd, alive);
+                                tp[(k + 1) & 1].template issue<false>(wg.base(a.vol[a.chan[0]]), wg.dims(), cs[sp ^ 1]);   // (speculative: dropped on leaving)
+                            }
+                            float sv, gm[3];
+                            tp[k & 1].template eval<STRICT>(cs[sp], sv, gm);
+                            const float w = a.weight[a.chan[c]];
+                            v = Mm::mad(sv, w, v);
+                            if constexpr (SHADE) {
+#pragma unroll
+                                for (int q = 0; q < 3; ++q) g[q] = Mm::mad(gm[q], w, g[q]);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        if (alive) { const Labels none = { 0u, 0u }; composite<STRICT, SHADE, GAMMA1, false>(a, rd, none, v, g, r); }
+                        t = alive ? tn : t;
+                        alive = alive && t < t1 && r.T > a.ert;
+                        if (__ballot(alive && dN == 0u) == 0 || __ballot(alive) == 0) { c0 = cs[sp ^ 1]; d0 = dN; out = true; }
+                    }
+                }
+                if (__ballot(alive) == 0) break;
+            }
+        }
+    } else if (marches) {
         float t = t0;
         Taps<LAYOUT, SHADE> tp[2];                                  // pair k lives in tp[k & 1]
         Cell cs[2];                                                 // cell of the step a pair belongs to: step parity
@@ -463,7 +540,9 @@ template <bool STRICT, int LAYOUT, bool SHADE, int NCH>
 static int launch_roll(const K1Args& a, hipStream_t s) {
     const dim3 grid(a.map.chunk * kXcds), block(a.map.blockPx == 8 ? 64 : 256);
     const bool overlays = a.showSeg != 0 || a.showPred != 0;
-    if (STRICT && a.gamma == 1.0f) {
+    if (a.skipDist != nullptr && !overlays && (!STRICT || a.gamma == 1.0f)) {      // (mrirt_render_brats_skip builds the map only then)
+        hipLaunchKernelGGL((brats_march_roll_kernel<STRICT, LAYOUT, SHADE, NCH, STRICT, false, true>), grid, block, 0, s, a);
+    } else if (STRICT && a.gamma == 1.0f) {
         if (overlays) hipLaunchKernelGGL((brats_march_roll_kernel<STRICT, LAYOUT, SHADE, NCH, STRICT, true>), grid, block, 0, s, a);
         else          hipLaunchKernelGGL((brats_march_roll_kernel<STRICT, LAYOUT, SHADE, NCH, STRICT, false>), grid, block, 0, s, a);
     } else {
@@ -503,7 +582,7 @@ static int launch(const K1Args& a, bool pipeAsked, hipStream_t s) {
     const bool pipe = pipeAsked && !((a.showSeg != 0 || a.showPred != 0) && labelElems >= (1ull << 30));
     if constexpr (LAYOUT == 2) {                      // VG: 8 float4 per modality per stage -> one modality; more: rolling pairs
         if (pipe && a.nch == 1 && !a.grid.wide) return launch_pipe<STRICT, 2, SHADE, 1>(a, s);
-        if (pipe && !a.grid.wide && a.skipDist == nullptr && a.showSeg == 0 && a.showPred == 0) {   // (with overlays the generic kernel measured faster)
+        if (pipe && !a.grid.wide && a.showSeg == 0 && a.showPred == 0) {   // (with overlays the generic kernel measured faster)
             switch (a.nch) {
                 case 2: return launch_roll<STRICT, 2, SHADE, 2>(a, s);
                 case 3: return launch_roll<STRICT, 2, SHADE, 3>(a, s);
@@ -514,7 +593,7 @@ static int launch(const K1Args& a, bool pipeAsked, hipStream_t s) {
     }
     if constexpr (LAYOUT == 4) {                      // VGA: as VG; every copy is < 4 GiB by construction (prepare())
         if (pipe && a.nch == 1) return launch_pipe<STRICT, 4, SHADE, 1>(a, s);
-        if (pipe && a.skipDist == nullptr && a.showSeg == 0 && a.showPred == 0) {
+        if (pipe && a.showSeg == 0 && a.showPred == 0) {
             switch (a.nch) {
                 case 2: return launch_roll<STRICT, 4, SHADE, 2>(a, s);
                 case 3: return launch_roll<STRICT, 4, SHADE, 3>(a, s);
@@ -1046,13 +1125,14 @@ extern "C" int mrirt_render_brats_skip(const MrirtBratsParams* p, const MrirtRen
     // window width and gamma (pow(0, g) = 0), non-negative weights (monotone sum), a bound for every enabled
     // modality and a label summary for every shown overlay.  Otherwise: the ordinary launch.
     bool ok = skip->mask != nullptr && p->ww > 0.0f && p->gamma > 0.0f && a.nch >= 1;
-    // ... and only where the launch below has a SKIP kernel: the pipelined kernel on VG / VGA grids with one modality or on
-    // QUAD grids (launch()), STRICT with gamma == 1 or FAST (launch_pipe()).  Anything else would pay the four pre-pass
-    // launches for a kernel that ignores the map — and, with several shaded modalities, lose the rolling kernel to the
-    // generic one (launch() takes a non-null skipDist as "not the rolling kernel": 0.87 vs 0.81 ms).
+    // ... and only where the launch below has a SKIP kernel: on VG / VGA grids the pipelined kernel (one modality) or the rolling
+    // kernel (2-4 modalities, no overlays), on QUAD grids the pipelined kernel (launch()); STRICT with gamma == 1, or FAST
+    // (launch_pipe() / launch_roll()).  Anything else would pay the four pre-pass launches for a kernel that ignores the map
+    // (with several shaded modalities + overlays that was the generic kernel, slower than without skip=True).
     {
         const bool wide = a.grid.wide != 0;
-        const bool layoutOk = ((cfg.layout == MRIRT_LAYOUT_VG && !wide) || cfg.layout == MRIRT_LAYOUT_VGA) ? a.nch == 1
+        const bool overlays = p->showSeg != 0 || p->showPred != 0;
+        const bool layoutOk = ((cfg.layout == MRIRT_LAYOUT_VG && !wide) || cfg.layout == MRIRT_LAYOUT_VGA) ? (a.nch == 1 || !overlays)   // pipelined / rolling
                             : (cfg.layout == MRIRT_LAYOUT_QUAD && !wide && !cfg.shade);
         const bool mathOk = cfg.math == MRIRT_MATH_FAST || p->gamma == 1.0f;
         ok = ok && cfg.pipe && !cfg.slab && layoutOk && mathOk;
@@ -1266,10 +1346,21 @@ extern "C" int mrirt_render_brats_inr(const MrirtBratsParams* p, const MrirtRend
     rc = c5_carve(p, chunk_steps, scratch, sc);
     if (rc != MRIRT_OK) return rc;
     if (scratch_bytes < sc.bytes) return MRIRT_ERR_ARG;
-    // passes: no ray takes more than diag / stepSize + 2 steps (prepare() has bounded that quotient)
-    double diag2 = 0.0;
-    for (int k = 0; k < 3; ++k) { const double e = (double)p->voxelSize[k] * (double)p->dims[k]; diag2 += e * e; }
-    const uint64_t maxSteps = (uint64_t)(sqrt(diag2) / (double)p->stepSize) + 3;
+    // passes: a ray's chord is at most the box diagonal; the march counts it with the running fp32 sum t += stepSize, whose
+    // increments are each off by up to half an ulp of t — a relative drift of up to ulp(tFar) / (2 stepSize) over the chord
+    // when stepSize is only a few tens of ulps of t.  The bound carries twice that drift (tFar = the farthest any
+    // sample can be, as in prepare()), so that no ray is still marching when the last pass has been composited.
+    double diag2 = 0.0, dist2 = 0.0;
+    for (int k = 0; k < 3; ++k) {
+        const double e = (double)p->voxelSize[k] * (double)p->dims[k];
+        const double c = (double)p->volMin[k] + 0.5 * e - (double)p->eye[k];
+        diag2 += e * e; dist2 += c * c;
+    }
+    double tFar = sqrt(dist2) + sqrt(diag2);
+    if (ext && ext->cameraMode == 1u) tFar += fabs((double)ext->orthoHalfHeight) * (1.0 + (double)p->imageSize[0] / fmax(1.0, (double)p->imageSize[1]));
+    const double ulpFar = (double)(nextafterf((float)tFar, INFINITY) - (float)tFar);
+    const double drift = 1.0 + ulpFar / (double)p->stepSize;
+    const uint64_t maxSteps = (uint64_t)(sqrt(diag2) / (double)p->stepSize * drift) + 3;
     const uint64_t passes = (maxSteps + chunk_steps - 1) / chunk_steps;
     if (passes > kC5MaxPasses) return MRIRT_ERR_ARG;
     EmitArgs e;

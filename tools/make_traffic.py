@@ -85,7 +85,8 @@ def main():
             on_chip["effective_clock_ghz"] = round(cyc / (stats_ms * 1e-3) / 1e9, 3)
         if "TCP_TOTAL_CACHE_ACCESSES_sum" in mean:
             entry["tcp_cache_line_accesses"] = round(mean["TCP_TOTAL_CACHE_ACCESSES_sum"])
-            # a CU's vector L1 looks up one 128-B line per clock: this fraction IS the utilisation of that roof
+            # line look-ups per clock per CU (NOT a roof by itself: the micro-benchmark reaches 0.93-0.99 with one line per quad or
+            # with bank conflicts, 1.67-1.76 with conflict-free multi-line quads)
             on_chip["l1_tag_accesses_per_clk_per_cu"] = round(mean["TCP_TOTAL_CACHE_ACCESSES_sum"] / cyc / CUS, 4)
         if "SQ_INSTS_VALU" in mean:
             entry["valu_instructions"] = round(mean["SQ_INSTS_VALU"])
@@ -94,6 +95,19 @@ def main():
             on_chip["valu_issue_fraction_of_peak"] = round(mean["SQ_INSTS_VALU"] * 2.0 / (SIMDS * cyc), 4)
         if "SQ_INSTS_VMEM_RD" in mean:
             entry["vmem_read_instructions"] = round(mean["SQ_INSTS_VMEM_RD"])
+            # what the texture path (TA -> vector L1 -> TD) spends per wave-level gather; tools/micro/tcp_tag_rate.hip measured the
+            # floor for all-hit dwordx4 gathers at 16.2-17.6 clk (one line per quad), 19.2 (two lines, different 16-B slots),
+            # 32 (two lines, same slot), 36 / 64 (four lines): profiles/r03_tcp_tag_rate.txt
+            on_chip["clk_per_wave_gather_per_cu"] = round(cyc * CUS / mean["SQ_INSTS_VMEM_RD"], 2)
+        if "TA_TA_BUSY_sum" in mean:
+            on_chip["ta_busy_fraction"] = round(mean["TA_TA_BUSY_sum"] / (cyc * CUS), 4)
+        if "TD_TD_BUSY_sum" in mean:
+            on_chip["td_busy_fraction"] = round(mean["TD_TD_BUSY_sum"] / (cyc * CUS), 4)
+        if "SQ_WAVE_CYCLES" in mean and "SQ_WAIT_ANY" in mean and "SQ_WAIT_INST_ANY" in mean:
+            wc = mean["SQ_WAVE_CYCLES"]
+            on_chip["wave_time"] = {"waiting_on_waitcnt": round(mean["SQ_WAIT_ANY"] / wc, 4),
+                                    "issue_stalled": round(mean["SQ_WAIT_INST_ANY"] / wc, 4),
+                                    "issuing": round(mean.get("SQ_ACTIVE_INST_ANY", 0.0) / wc, 4)}
         if "SQ_INSTS_LDS" in mean:
             entry["lds_instructions"] = round(mean["SQ_INSTS_LDS"])
         if "SQ_BUSY_CYCLES" in mean and "SQ_ACTIVE_INST_VALU" in mean:
