@@ -171,6 +171,24 @@ def test_skip_with_several_shaded_modalities_rolling_kernel(layout, channels, ma
     assert int((render._last_skip_mask != 0x5a5a5a5a).sum()) == 0 or render._last_skip_mask is not raw
 
 
+def test_skip_switches_itself_off_on_a_volume_without_empty_space():
+    """The synthetic bench volume has no air: the map of its first skipping frame says so (one read-back when the map is
+    first reused), and later frames take the plain kernels — same bits, no skipping overhead."""
+    import torch
+    import mrirt
+    from mrirt import synth, render
+    n = 64
+    vol = synth.synth_volume(n)
+    g = mrirt.upload_grid(vol, (n, n, n), "quad")
+    p = synth.brats_scene(n, 128, 96, channels=1, intensity_alpha=4.0)
+    plain = mrirt.render_brats(p, [g])
+    render._SKIP_MAPS.clear()
+    frames = [mrirt.render_brats(p, [g], skip=True) for _ in range(3)]
+    assert all(torch.equal(f, plain) for f in frames)
+    (entry,) = render._SKIP_MAPS.values()
+    assert entry[2][0] is not None and entry[2][0] < render.SKIP_MIN_EMPTY_FRACTION
+
+
 def test_skip_with_tile_sharding():
     """Tiles of three 'ranks' rendered with skipping reassemble to the plain whole frame."""
     import torch

@@ -16,8 +16,8 @@ lab = synth.synth_labels(0, dims=dims)
 pred = np.roll(lab, 3).copy()
 p = synth.brats_scene(0, 0, 64, dims=dims, image_hw=(H, W), channels=4, show_seg=True, show_pred=True, intensity_alpha=0.4)
 p["stepSize"] = np.float32(0.05)
-for layout in ("auto", "linear"):
-    dev = spy.Device(layout=layout)
+for layout, skip in (("auto", True), ("auto", False), ("linear", True)):
+    dev = spy.Device(layout=layout, skip_empty=skip)
     k = dev.create_compute_kernel(dev.load_program("brats_rt.slang", ["brats_main"]))
     bufs = []
     for a in vols + [lab, pred]:
@@ -35,4 +35,4 @@ for layout in ("auto", "linear"):
         k.dispatch(thread_count=[W, H, 1], vars=vars_)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 50
-    print(f"viewer frame {W}x{H}, {dims}, 4 modalities + seg + pred, stepSize 0.05, Device(layout={layout!r}): {ms:.3f} ms per dispatch incl. Python ({1000 / ms:.0f} frames/s)")
+    print(f"viewer frame {W}x{H}, {dims}, 4 modalities + seg + pred, stepSize 0.05, Device(layout={layout!r}, skip_empty={skip}): {ms:.3f} ms per dispatch incl. Python ({1000 / ms:.0f} frames/s)")
