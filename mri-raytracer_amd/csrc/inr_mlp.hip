@@ -938,14 +938,21 @@ __global__ __launch_bounds__(256, 1) void inr_ws_kernel(const InrArgs a) {
             };
             constexpr int NP = 2 * G;
             f32x16 acc = bias_tile(0, 0), accPrev, accNext;
-            bf16x8 Ho[2], Bin[2];
+            bf16x8 Ho[2];
+            // the four layer-0 A fragments of this wave's two tiles are read ONCE per phase, the input fragments one group ahead:
+            // read pass by pass right in front of their MFMAs, every pass exposed an LDS round trip (round 2's stamps: 3.6 k
+            // cycles for a phase whose MFMA + VALU work is ~2 k).
+            bf16x8 wa[4], Bin[2], BinNext[2];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) wa[q] = __builtin_bit_cast(bf16x8, bWt[q * 64]);
+            Bin[0] = __builtin_bit_cast(bf16x8, bIn[0]); Bin[1] = __builtin_bit_cast(bf16x8, bIn[64]);
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
                 const int g = i >> 1, j = i & 1;
-                if (j == 0) { Bin[0] = __builtin_bit_cast(bf16x8, bIn[(g * 2 + 0) * 64]); Bin[1] = __builtin_bit_cast(bf16x8, bIn[(g * 2 + 1) * 64]); }
-                const bf16x8 wa0 = __builtin_bit_cast(bf16x8, bWt[(2 * j + 0) * 64]), wa1 = __builtin_bit_cast(bf16x8, bWt[(2 * j + 1) * 64]);
-                mfma_v(acc, wa0, Bin[0]);
-                mfma_v(acc, wa1, Bin[1]);
+                if (j == 0 && g + 1 < G) { BinNext[0] = __builtin_bit_cast(bf16x8, bIn[((g + 1) * 2 + 0) * 64]); BinNext[1] = __builtin_bit_cast(bf16x8, bIn[((g + 1) * 2 + 1) * 64]); }
+                mfma_v(acc, wa[2 * j + 0], Bin[0]);
+                mfma_v(acc, wa[2 * j + 1], Bin[1]);
+                if (j == 1) { Bin[0] = BinNext[0]; Bin[1] = BinNext[1]; }
                 __builtin_amdgcn_sched_barrier(0);
                 if (i + 1 < NP) accNext = bias_tile(0, (i + 1) & 1);
                 if (i > 0) {
