@@ -15,7 +15,7 @@ PKG_DIR = pathlib.Path(__file__).resolve().parent
 CSRC = PKG_DIR / "csrc"
 INCLUDE = PKG_DIR.parent / "include"
 SO_PATH = pathlib.Path(os.environ.get("MRIRT_LIB", PKG_DIR / "libmrirt.so"))   # override: A/B builds in development
-HIP_SOURCES = ["brats_march.hip", "brats_slab.hip", "volume_march.hip", "grid_ops.hip", "inr_mlp.hip"]
+HIP_SOURCES = ["brats_march.hip", "brats_slab.hip", "brats_ring.hip", "volume_march.hip", "grid_ops.hip", "inr_mlp.hip"]
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17", "-Wall"]
 
 # every extern "C" symbol include/mrirt.h declares

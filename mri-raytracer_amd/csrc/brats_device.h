@@ -414,5 +414,7 @@ __device__ __forceinline__ void finish(const K1Args& a, int kind, int64_t oidx, 
 
 // brats_slab.hip: the LDS-staged march (VGA layout, one modality, no overlays), selected by brats_march.hip
 int launch_slab_march(const K1Args& a, bool strict, bool shade, hipStream_t s);
+// brats_ring.hip: the plane-synchronous LDS ring march (same launches)
+int launch_ring_march(const K1Args& a, bool strict, bool shade, hipStream_t s);
 
 }  // namespace mrirt

@@ -887,7 +887,7 @@ __global__ __launch_bounds__(256) void c5_composite_kernel(const K1Args a, C5Ray
     finish(a, kind, oidx, r);      // the frame so far (complete after the last pass); live-sample counters
 }
 
-struct Prepared { uint32_t layout, math; bool shade, pipe, slab; };
+struct Prepared { uint32_t layout, math; bool shade, pipe, slab, ring; };
 
 // validate + fill the kernel arguments shared by every K1 entry point
 static int prepare(const MrirtBratsParams* p, const MrirtRenderExt* ext, const void* const vol[4],
@@ -946,7 +946,7 @@ static int prepare(const MrirtBratsParams* p, const MrirtRenderExt* ext, const v
     if (ext && ext->tileSize != 0 && ext->tileWorld != 0)
         blocks16 = (uint64_t)mrirt_tiles_for_rank(p->imageSize[0], p->imageSize[1], ext->tileSize, ext->tileRank, ext->tileWorld) *
                    ((ext->tileSize + 15u) / 16u) * ((ext->tileSize + 15u) / 16u);
-    const bool bigBlocks = ((variant & 2u) != 0u) != (layout == MRIRT_LAYOUT_VGA && (variant & 64u) == 0u && blocks16 >= 4096u);
+    const bool bigBlocks = ((variant & 2u) != 0u) != (layout == MRIRT_LAYOUT_VGA && (variant & (64u | 2048u)) == 0u && blocks16 >= 4096u);
     // XCD-interleaved bands one workgroup row high by default (8-px bands for 8 x 8 workgroups: config 2 0.606 -> 0.580 ms,
     // K1 at 512^3 level; variant bit 3: contiguous run per XCD; bits 4-5: 16 / 8 / 32 / 64 px)
     const uint32_t bandSel = (variant >> 4) & 3u;
@@ -1013,6 +1013,9 @@ static int prepare(const MrirtBratsParams* p, const MrirtRenderExt* ext, const v
     // the LDS-staged kernel (brats_slab.hip): VGA grids, one modality, no overlays, one packet per workgroup; variant bit 6
     cfg.slab = layout == MRIRT_LAYOUT_VGA && (variant & 64u) != 0 && cfg.pipe && a.nch == 1 && p->showSeg == 0 && p->showPred == 0 &&
                a.map.blockPx == 8;
+    // the plane-synchronous LDS ring kernel (brats_ring.hip): the same launches; variant bit 11
+    cfg.ring = layout == MRIRT_LAYOUT_VGA && (variant & 2048u) != 0 && (variant & 64u) == 0 && cfg.pipe && a.nch == 1 && p->showSeg == 0 &&
+               p->showPred == 0 && a.map.blockPx == 8 && p->dims[0] >= 16 && p->dims[1] >= 16 && p->dims[2] >= 16;
     return MRIRT_OK;
 }
 
@@ -1102,6 +1105,7 @@ extern "C" int mrirt_render_brats_ex(const MrirtBratsParams* p, const MrirtRende
     if (a.map.numBlocks == 0) return MRIRT_OK;   // a rank that owns no tile
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (cfg.slab) return launch_slab_march(a, cfg.math == MRIRT_MATH_STRICT, cfg.shade, s);
+    if (cfg.ring) return launch_ring_march(a, cfg.math == MRIRT_MATH_STRICT, cfg.shade, s);
     return cfg.math == MRIRT_MATH_STRICT ? launch_layout<true>(a, cfg.layout, cfg.shade, cfg.pipe, s)
                                          : launch_layout<false>(a, cfg.layout, cfg.shade, cfg.pipe, s);
 }
