@@ -1007,6 +1007,7 @@ static int prepare(const MrirtBratsParams* p, const MrirtRenderExt* ext, const v
     a.expSmall = (fabsf(p->intensityAlpha * p->stepSize) <= 0.125f) ? 1u : 0u;   // val is in [0, 1]
     a.out = nullptr; a.stats = nullptr;
     a.debugFlags = (variant >> 7) & 15u;
+    if (variant & 4096u) a.debugFlags |= 32u;                          // ring kernel: three planes instead of four
     cfg.layout = layout; cfg.math = math;
     cfg.shade = ext && ext->shadeMode != 0;
     cfg.pipe = a.nch >= 1 && !(variant & 4u);

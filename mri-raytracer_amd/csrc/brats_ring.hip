@@ -34,7 +34,6 @@
 
 namespace mrirt {
 
-constexpr int kRingPlanes = 4;
 constexpr int kRingPlaneQ = 256;                 // float4 per plane window (16 x 16 voxels)
 
 // smallest value over the wave (every lane takes part), DPP reduction; result uniform
@@ -119,7 +118,7 @@ template <int A> struct RingAxes {
     static constexpr int V = A == 2 ? 1 : 2;     // its 2-voxel side
 };
 
-template <bool STRICT, bool SHADE, bool GAMMA1, int A>
+template <bool STRICT, bool SHADE, bool GAMMA1, int A, int R>
 __device__ __forceinline__ void march_ring(const K1Args& a, const RingGeom& gm, float4* ring, const float ro[3], const float rd[3],
                                            float t0, float t1, bool marches, RayState& r) {
     constexpr int U = RingAxes<A>::U, V = RingAxes<A>::V;
@@ -129,44 +128,60 @@ __device__ __forceinline__ void march_ring(const K1Args& a, const RingGeom& gm, 
     const char* lds = reinterpret_cast<const char*>(ring);
 
     // ---- the loader's side: lane L of piece j fills LDS row 4j + (L >> 4), column L & 15 of the plane's slot ----
+    // Planes are filled strictly in march order, so everything that depends on the plane is a running scalar value:
+    // the hull bounds (fixed point), the plane's byte offset, the ring slot.
     const uint32_t cu = ((lane & 15u) - 4u * (lane >> 4)) & 15u;      // iu mod 16 of the voxel this lane moves (column skew undone)
     int curLu0 = -1, curLv0 = -1;
     uint32_t offU = 0u, offV[4] = { 0u, 0u, 0u, 0u };                 // float4 elements inside the plane
-    int iuL = 0, ivL[4] = { 0, 0, 0, 0 };                             // ... and the voxel itself (which lanes a fill needs)
-    auto load_plane = [&](int q) {                                    // every lane takes part: EXEC is all ones here
+    const int dLoU = gm.fwd ? gm.loUs : -gm.loUs, dLoV = gm.fwd ? gm.loVs : -gm.loVs, dHiV = gm.fwd ? gm.hiVs : -gm.hiVs;
+    const int64_t planeBytes = (int64_t)gm.mulA << 4, dPb = gm.fwd ? planeBytes : -planeBytes;
+    int qNext = 0, slotNext = 0, loUc = 0, loVc = 0, hiVc = 0;
+    int64_t pbOff = 0;
+    auto seek = [&](int q) {                                          // the next fill is march plane q, into slot 0
         const int p = gm.fwd ? q : -q;
-        const int pc = min(max(p, 0), gm.dimA1);                      // (planes outside the grid are never read)
-        int lu0, lv0;
-        ring_origin(gm, pc, lu0, lv0);
-        if (lu0 != curLu0) {                                          // uniform: every few planes
-            curLu0 = lu0;
-            const uint32_t iu = 4u * (uint32_t)lu0 + ((cu - 4u * (uint32_t)lu0) & 15u);
-            offU = (iu >> 2) * gm.mulU + (iu & 3u);
-            iuL = (int)iu;
-        }
-        if (lv0 != curLv0) {
-            curLv0 = lv0;
+        qNext = q; slotNext = 0;
+        loUc = gm.loU0 + p * gm.loUs;
+        loVc = gm.loV0 + p * gm.loVs; hiVc = gm.hiV0 + p * gm.hiVs;
+        pbOff = (int64_t)p * planeBytes;
+    };
+    auto load_next = [&]() {                                          // every lane takes part: EXEC is all ones here
+        const int p = gm.fwd ? qNext : -qNext;
+        if ((uint32_t)p <= (uint32_t)gm.dimA1 && (a.debugFlags & 2u) == 0u) {   // (planes outside the grid are never read; kernelVariant bit 8: no fills)
+            // a sample between the last lattice plane and the box face is clamped into the last cell and reads planes
+            // dimA - 2, dimA - 1 from up to two planes away: plane dimA - 2 is widened by one more slope
+            const int last = p == gm.dimA1 - 1 ? 1 : 0;
+            const int loU = loUc - last * gm.lastU, loV = loVc - last * gm.lastV, hiV = hiVc + last * gm.lastV;
+            const int lu0 = min(max(loU >> 18, 0), gm.nbU4), lv0 = min(max(loV >> 17, 0), gm.nbV8);
+            if (lu0 != curLu0) {                                      // uniform: every few planes
+                curLu0 = lu0;
+                const uint32_t iu = 4u * (uint32_t)lu0 + ((cu - 4u * (uint32_t)lu0) & 15u);
+                offU = (iu >> 2) * gm.mulU + (iu & 3u);
+            }
+            if (lv0 != curLv0) {
+                curLv0 = lv0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t iv = 2u * (uint32_t)lv0 + ((4u * j + (lane >> 4) - 2u * (uint32_t)lv0) & 15u);
+                    offV[j] = (iv >> 1) * gm.mulV + 4u * (iv & 1u);
+                }
+            }
+            // Which of the four pieces (four window rows each) the beam can touch on this plane: rows 2 lv0 .. floor(hi) + 1
+            // of the window (the beam's lower edge sits in the first line).  Piece j holds window rows (4 j - 2 lv0) & 15 and the
+            // next three, modulo 16: the piece that wraps holds rows 0, 1 and is always wanted.  Whole pieces only (a
+            // wave-uniform test; a 16 x 16 window is ~2x what an 8 x 8-pixel beam needs, a quarter of it goes this way).
+            const int hRel = max((hiV >> 16) + 1, 1) - 2 * lv0;
+            const char* pbase = vbase + pbOff;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const uint32_t iv = 2u * (uint32_t)lv0 + ((4u * j + (lane >> 4) - 2u * (uint32_t)lv0) & 15u);
-                offV[j] = (iv >> 1) * gm.mulV + 4u * (iv & 1u);
-                ivL[j] = (int)iv;
+                const int base = (4 * j - 2 * lv0) & 15;
+                if (base == 14 || base <= hRel)
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void*)(pbase + (size_t)((offU + offV[j]) << 4)),
+                        (__attribute__((address_space(3))) void*)(&ring[slotNext * kRingPlaneQ + j * 64]), 16, 0, 0);
             }
         }
-        const char* pbase = vbase + (((uint64_t)(uint32_t)pc * gm.mulA) << 4);
-        const int slot = q & (kRingPlanes - 1);
-        // only the voxels the beam can touch on this plane (ring_need): a 16 x 16 window holds ~2x what an 8 x 8-pixel beam
-        // needs; the rest stays stale, unread
-        int uLo, uHi, vLo, vHi;
-        ring_need(gm, pc, uLo, uHi, vLo, vHi);
-        const bool needU = iuL >= uLo && iuL <= uHi && (a.debugFlags & 2u) == 0u;      // (kernelVariant bit 8: no fills at all — timing experiments, wrong frame)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (needU && ivL[j] >= vLo && ivL[j] <= vHi)
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void*)(pbase + (size_t)((offU + offV[j]) << 4)),
-                    (__attribute__((address_space(3))) void*)(&ring[slot * kRingPlaneQ + j * 64]), 16, 0, 0);
-        }
+        ++qNext; slotNext = slotNext + 1 == R ? 0 : slotNext + 1;
+        loUc += dLoU; loVc += dLoV; hiVc += dHiV; pbOff += dPb;
     };
     // march-order index of the lower plane of a cell: planes qa, qa + 1 (ascending: ia, ia + 1; descending: ia + 1, ia)
     auto cell_q = [&](const Cell& s) {
@@ -179,14 +194,18 @@ __device__ __forceinline__ void march_ring(const K1Args& a, const RingGeom& gm, 
     Cell s;
     locate<STRICT>(a, ro, rd, t, s);
     int qa = cell_q(s);
-    int tail = wave_min_i32(alive ? qa : 0x7fffffff);
-    for (int k = 0; k < kRingPlanes; ++k) load_plane(tail + k);
+    int tail = wave_min_i32(alive ? qa : 0x7fffffff);                 // the ring holds march planes [tail, tail + R - 1]
+    int tailSlot = 0;                                                 // ... plane tail + i in slot (tailSlot + i) mod R
+    seek(tail);
+#pragma nounroll
+    for (int k = 0; k < R; ++k) load_next();
 
     const float w = a.weight[a.chan[0]];
     const Labels none = { 0u, 0u };
     while (true) {
-        // this round's readers: the sample's planes qa, qa + 1 are inside [tail, tail + 3]
-        const bool can = alive && qa - tail <= kRingPlanes - 2;
+        // this round's readers: the sample's planes qa, qa + 1 are resident
+        const int dq = qa - tail;                                     // >= 0 for every lane that may still live
+        const bool can = alive && dq <= R - 2 && qa + 1 < qNext;      // (qNext: a long step may outrun the two fills a round makes)
         Taps<4, SHADE> taps;
         if (a.debugFlags & 4u) {                                      // diagnostic (kernelVariant bit 9): stats[1] = shaded + lane-rounds spent idle;
             if (a.debugFlags & 1u) r.nShaded += lane == 0u ? 1u : 0u; //   with bit 7 as well: shaded + rounds (one per wave and round)
@@ -194,11 +213,15 @@ __device__ __forceinline__ void march_ring(const K1Args& a, const RingGeom& gm, 
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // every plane requested so far has landed
         if (can) {
-            const uint32_t ia = A == 0 ? s.ix : (A == 1 ? s.iy : s.iz);
             const uint32_t iu = U == 0 ? s.ix : s.iy, iv = V == 1 ? s.iy : s.iz;
-            const int qv = gm.fwd ? (int)ia : -(int)ia;               // march index of plane ia; plane ia + 1 is one further / nearer
-            const uint32_t s0 = ((uint32_t)qv << 12) & 0x3000u;
-            const uint32_t s1 = ((uint32_t)(gm.fwd ? qv + 1 : qv - 1) << 12) & 0x3000u;
+            // byte offsets of the slots of march planes tail + dq (the cell's first plane) and tail + dq + 1
+            uint32_t sb[R];
+#pragma unroll
+            for (int i = 0; i < R; ++i) { const int sl = tailSlot + i; sb[i] = (uint32_t)(sl >= R ? sl - R : sl) << 12; }
+            uint32_t sFirst = sb[0], sSecond = sb[1];
+#pragma unroll
+            for (int i = 1; i <= R - 2; ++i) { sFirst = dq == i ? sb[i] : sFirst; sSecond = dq == i ? sb[i + 1] : sSecond; }
+            const uint32_t s0 = gm.fwd ? sFirst : sSecond, s1 = gm.fwd ? sSecond : sFirst;     // planes ia, ia + 1
             const uint32_t g0 = (iv << 8) & 0xf00u, g1 = ((iv + 1u) << 8) & 0xf00u;
             const uint32_t cs = (iu + 4u * iv) << 4;                  // column (skewed), in bytes
             const uint32_t f00 = cs & 0xf0u, f10 = (cs + 16u) & 0xf0u, f01 = (cs + 64u) & 0xf0u, f11 = (cs + 80u) & 0xf0u;
@@ -210,6 +233,7 @@ __device__ __forceinline__ void march_ring(const K1Args& a, const RingGeom& gm, 
                 taps.c[c] = *reinterpret_cast<const float4*>(lds + off);
             }
             if ((a.debugFlags & 5u) == 1u) {                          // diagnostic (kernelVariant bit 7): stats[1] = shaded + reads outside a window
+                const uint32_t ia = A == 0 ? s.ix : (A == 1 ? s.iy : s.iz);
                 bool bad = false;
 #pragma unroll
                 for (int dp = 0; dp < 2; ++dp) {
@@ -218,8 +242,8 @@ __device__ __forceinline__ void march_ring(const K1Args& a, const RingGeom& gm, 
                     ring_origin(gm, p, lu0, lv0);
                     bad = bad || (int)iu < 4 * lu0 || (int)iu + 1 > 4 * lu0 + 15 || (int)iv < 2 * lv0 || (int)iv + 1 > 2 * lv0 + 15;
                     int uLo, uHi, vLo, vHi;
-                    ring_need(gm, p, uLo, uHi, vLo, vHi);
-                    bad = bad || (int)iu < uLo || (int)iu + 1 > uHi || (int)iv < vLo || (int)iv + 1 > vHi;
+                    ring_need(gm, p, uLo, uHi, vLo, vHi);                 // rows beyond vHi may not have been brought (whole pieces are)
+                    bad = bad || (int)iv + 1 > vHi;
                 }
                 r.nShaded += bad ? 1u : 0u;
             }
@@ -231,11 +255,24 @@ __device__ __forceinline__ void march_ring(const K1Args& a, const RingGeom& gm, 
         locate<STRICT>(a, ro, rd, tn, sn);
         const int qn = cell_q(sn);
         const bool mayLive = alive && tn < t1;
-        const int tailN = wave_min_i32(mayLive ? qn : 0x7fffffff);
+        // the new tail = the smallest qn: nearly always tail, tail + 1 or tail + 2 — three ballots instead of a reduction
+        const int dn = mayLive ? qn - tail : 0x7fffffff;
+        int adv;
+        if (__ballot(dn == 0) != 0) adv = 0;
+        else if (__ballot(dn == 1) != 0) adv = 1;
+        else if (__ballot(dn == 2) != 0) adv = 2;
+        else adv = wave_min_i32(dn);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // the taps are in registers: their slots may be refilled
-        if (tailN != 0x7fffffff) {
-            for (int q = max(tail + kRingPlanes, tailN); q < tailN + kRingPlanes; ++q) load_plane(q);
-            tail = tailN;
+        if (adv != 0x7fffffff) {
+            tail += adv;
+            if (tail > qNext) {                                       // the rays that held the ring back have ended: start over further on
+                seek(tail); tailSlot = 0;
+            } else {
+                tailSlot += adv < R ? adv : adv % R;
+                tailSlot = tailSlot >= R ? tailSlot - R : tailSlot;
+            }
+            if (qNext < tail + R) load_next();                        // two fills per round at most: rays advance <= 1.73 planes per step
+            if (qNext < tail + R) load_next();                        // (longer steps: rounds in which nobody reads catch up)
         }
         if (can) {
             float sv, g[3] = { 0.0f, 0.0f, 0.0f };
@@ -257,9 +294,9 @@ __device__ __forceinline__ void march_ring(const K1Args& a, const RingGeom& gm, 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // nothing may still be writing this workgroup's LDS
 }
 
-template <bool STRICT, bool SHADE, bool GAMMA1>
+template <bool STRICT, bool SHADE, bool GAMMA1, int R>
 __global__ __launch_bounds__(64) void brats_march_ring_kernel(const K1Args a) {
-    __shared__ float4 ring[kRingPlanes * kRingPlaneQ];
+    __shared__ float4 ring[R * kRingPlaneQ];
     uint32_t px, py;
     int64_t oidx;
     const int kind = map_pixel(a.map, px, py, oidx);
@@ -360,17 +397,24 @@ __global__ __launch_bounds__(64) void brats_march_ring_kernel(const K1Args a) {
     gm.lastU = __builtin_amdgcn_readfirstlane((int)ceilf(maxKU * 65536.0f)); gm.lastV = __builtin_amdgcn_readfirstlane((int)ceilf(maxKV * 65536.0f));
     gm.loU0 = __builtin_amdgcn_readfirstlane(gm.loU0); gm.loUs = __builtin_amdgcn_readfirstlane(gm.loUs);
     gm.loV0 = __builtin_amdgcn_readfirstlane(gm.loV0); gm.loVs = __builtin_amdgcn_readfirstlane(gm.loVs);
-    if (A == 0)      march_ring<STRICT, SHADE, GAMMA1, 0>(a, gm, ring, ro, rd, t0, t1, marches, r);
-    else if (A == 1) march_ring<STRICT, SHADE, GAMMA1, 1>(a, gm, ring, ro, rd, t0, t1, marches, r);
-    else             march_ring<STRICT, SHADE, GAMMA1, 2>(a, gm, ring, ro, rd, t0, t1, marches, r);
+    if (A == 0)      march_ring<STRICT, SHADE, GAMMA1, 0, R>(a, gm, ring, ro, rd, t0, t1, marches, r);
+    else if (A == 1) march_ring<STRICT, SHADE, GAMMA1, 1, R>(a, gm, ring, ro, rd, t0, t1, marches, r);
+    else             march_ring<STRICT, SHADE, GAMMA1, 2, R>(a, gm, ring, ro, rd, t0, t1, marches, r);
     finish(a, kind, oidx, r);
 }
 
 template <bool STRICT, bool SHADE>
 static int launch_ring_t(const K1Args& a, hipStream_t s) {
     const dim3 grid(a.map.chunk * kXcds), block(64);
-    if (STRICT && a.gamma == 1.0f) hipLaunchKernelGGL((brats_march_ring_kernel<STRICT, SHADE, STRICT>), grid, block, 0, s, a);
-    else                           hipLaunchKernelGGL((brats_march_ring_kernel<STRICT, SHADE, false>), grid, block, 0, s, a);
+    // ring depth: 4 planes serve rays of any phase at full rate; 3 (kernelVariant bit 12) trade that for 13 instead of 10 waves per CU
+    const bool r3 = (a.debugFlags & 32u) != 0u;
+    if (STRICT && a.gamma == 1.0f) {
+        if (r3) hipLaunchKernelGGL((brats_march_ring_kernel<STRICT, SHADE, STRICT, 3>), grid, block, 0, s, a);
+        else    hipLaunchKernelGGL((brats_march_ring_kernel<STRICT, SHADE, STRICT, 4>), grid, block, 0, s, a);
+    } else {
+        if (r3) hipLaunchKernelGGL((brats_march_ring_kernel<STRICT, SHADE, false, 3>), grid, block, 0, s, a);
+        else    hipLaunchKernelGGL((brats_march_ring_kernel<STRICT, SHADE, false, 4>), grid, block, 0, s, a);
+    }
     MRIRT_HIP(hipGetLastError());
     return MRIRT_OK;
 }
