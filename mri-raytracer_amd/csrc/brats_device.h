@@ -243,8 +243,18 @@ template <int LAYOUT, bool SHADE> struct TapsScalar {        // LINEAR / BRICK f
         const uint32_t y0 = A::oy(gd, s.iy), y1 = A::oy(gd, s.iy + 1);
         const uint32_t z0 = A::oz(gd, s.iz), z1 = A::oz(gd, s.iz + 1);
         // core 2x2x2 (sampleLinear, brats_rt.slang:69-72)
-        c[0] = buf[x0 + y0 + z0]; c[1] = buf[x1 + y0 + z0]; c[2] = buf[x0 + y1 + z0]; c[3] = buf[x1 + y1 + z0];
-        c[4] = buf[x0 + y0 + z1]; c[5] = buf[x1 + y0 + z1]; c[6] = buf[x0 + y1 + z1]; c[7] = buf[x1 + y1 + z1];
+        if constexpr (LAYOUT == 0) {
+            // the reference's own buffers (x fastest): the clamp dims - 1.001 keeps ix <= X - 2, so the x + 1 neighbour is the
+            // next word — four 8-byte gathers (4-byte aligned: global memory takes them) instead of eight 4-byte ones.  The
+            // texture path charges per wave-level instruction, so this halves the cost of the plain ABI's march.
+            struct __attribute__((packed, aligned(4))) Pair { float a, b; };
+            const Pair p00 = *reinterpret_cast<const Pair*>(buf + (x0 + y0 + z0)), p10 = *reinterpret_cast<const Pair*>(buf + (x0 + y1 + z0));
+            const Pair p01 = *reinterpret_cast<const Pair*>(buf + (x0 + y0 + z1)), p11 = *reinterpret_cast<const Pair*>(buf + (x0 + y1 + z1));
+            c[0] = p00.a; c[1] = p00.b; c[2] = p10.a; c[3] = p10.b; c[4] = p01.a; c[5] = p01.b; c[6] = p11.a; c[7] = p11.b;
+        } else {
+            c[0] = buf[x0 + y0 + z0]; c[1] = buf[x1 + y0 + z0]; c[2] = buf[x0 + y1 + z0]; c[3] = buf[x1 + y1 + z0];
+            c[4] = buf[x0 + y0 + z1]; c[5] = buf[x1 + y0 + z1]; c[6] = buf[x0 + y1 + z1]; c[7] = buf[x1 + y1 + z1];
+        }
         if constexpr (SHADE) {
             const uint32_t xm = A::ox(gd, s.ix > 0 ? s.ix - 1 : 0), xp = A::ox(gd, min(s.ix + 2, gd.X - 1));
             const uint32_t ym = A::oy(gd, s.iy > 0 ? s.iy - 1 : 0), yp = A::oy(gd, min(s.iy + 2, gd.Y - 1));
