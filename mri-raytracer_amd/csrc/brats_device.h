@@ -232,6 +232,8 @@ template <> struct Taps<3, false> {                  // QUAD: the z and z+1 xy-q
     }
 };
 
+struct __attribute__((packed, aligned(4))) LinearPair { float a, b; };   // two x-neighbours of a LINEAR grid: one 8-byte gather
+
 template <int LAYOUT, bool SHADE> struct TapsScalar {        // LINEAR / BRICK fp32 grids
     float c[8];
     float n[SHADE ? 24 : 1];                                 // +-1 neighbours of the 8 corners per axis
@@ -245,11 +247,9 @@ template <int LAYOUT, bool SHADE> struct TapsScalar {        // LINEAR / BRICK f
         // core 2x2x2 (sampleLinear, brats_rt.slang:69-72)
         if constexpr (LAYOUT == 0) {
             // the reference's own buffers (x fastest): the clamp dims - 1.001 keeps ix <= X - 2, so the x + 1 neighbour is the
-            // next word — four 8-byte gathers (4-byte aligned: global memory takes them) instead of eight 4-byte ones.  The
-            // texture path charges per wave-level instruction, so this halves the cost of the plain ABI's march.
-            struct __attribute__((packed, aligned(4))) Pair { float a, b; };
-            const Pair p00 = *reinterpret_cast<const Pair*>(buf + (x0 + y0 + z0)), p10 = *reinterpret_cast<const Pair*>(buf + (x0 + y1 + z0));
-            const Pair p01 = *reinterpret_cast<const Pair*>(buf + (x0 + y0 + z1)), p11 = *reinterpret_cast<const Pair*>(buf + (x0 + y1 + z1));
+            // next word — four 8-byte gathers (4-byte aligned: global memory takes them) instead of eight 4-byte ones
+            const LinearPair p00 = *reinterpret_cast<const LinearPair*>(buf + (x0 + y0 + z0)), p10 = *reinterpret_cast<const LinearPair*>(buf + (x0 + y1 + z0));
+            const LinearPair p01 = *reinterpret_cast<const LinearPair*>(buf + (x0 + y0 + z1)), p11 = *reinterpret_cast<const LinearPair*>(buf + (x0 + y1 + z1));
             c[0] = p00.a; c[1] = p00.b; c[2] = p10.a; c[3] = p10.b; c[4] = p01.a; c[5] = p01.b; c[6] = p11.a; c[7] = p11.b;
         } else {
             c[0] = buf[x0 + y0 + z0]; c[1] = buf[x1 + y0 + z0]; c[2] = buf[x0 + y1 + z0]; c[3] = buf[x1 + y1 + z0];
@@ -281,7 +281,37 @@ template <int LAYOUT, bool SHADE> struct TapsScalar {        // LINEAR / BRICK f
         }
     }
 };
-template <bool SHADE> struct Taps<0, SHADE> : TapsScalar<0, SHADE> {};
+template <> struct Taps<0, true> : TapsScalar<0, true> {};
+// LINEAR, unshaded — the plain ABI's march on the reference's own buffers (mrirt_render_brats): the cell's four x-pairs
+// (y, z) in {0, 1}^2 as 8-byte gathers, kept as register pairs so that the pipelined kernel can issue them as asm
+// (async_load_pair) and retire a whole stage with one wait, like the float4 layouts.
+__device__ __forceinline__ void async_load_pair(f32x2& dst, const void* __restrict__ base, uint32_t byteOff) {
+    f32x2 t;
+    asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(t) : "v"(byteOff), "s"(base));
+    dst = t;
+}
+template <> struct Taps<0, false> {
+    f32x2 p[4];                                      // (x0, x1) at (y0, z0), (y1, z0), (y0, z1), (y1, z1)
+    template <bool WIDE>
+    __device__ __forceinline__ void issue(const void* __restrict__ vbuf, const GridDims& gd, const Cell& s) {
+        const float* __restrict__ buf = static_cast<const float*>(vbuf);
+        const uint32_t o = s.ix + s.iy * gd.sY + s.iz * gd.sZ;
+        const uint32_t off[4] = { o, o + gd.sY, o + gd.sZ, o + gd.sY + gd.sZ };
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const LinearPair q = *reinterpret_cast<const LinearPair*>(buf + off[i]);
+            p[i] = f32x2{ q.a, q.b };
+        }
+    }
+    __device__ __forceinline__ void issue_async(const void* __restrict__ vbuf, const CellOffsets& k) {   // k in ELEMENTS (floats); grid < 4 GiB
+        async_load_pair(p[0], vbuf, k.o << 2);           async_load_pair(p[1], vbuf, (k.o + k.dy) << 2);
+        async_load_pair(p[2], vbuf, (k.o + k.dz) << 2);  async_load_pair(p[3], vbuf, (k.o + k.dy + k.dz) << 2);
+    }
+    template <bool STRICT>
+    __device__ __forceinline__ void eval(const Cell& s, float& v, float*) const {
+        v = trilerp<STRICT>(p[0].x, p[0].y, p[1].x, p[1].y, p[2].x, p[2].y, p[3].x, p[3].y, s.fx, s.fy, s.fz);
+    }
+};
 template <bool SHADE> struct Taps<1, SHADE> : TapsScalar<1, SHADE> {};
 
 __device__ __forceinline__ uint32_t sample_label(const uint32_t* __restrict__ buf, const LabelAddr& la,

@@ -156,11 +156,12 @@ struct Stage {
     // loads into a divergent branch, and a load the compiler cannot count past turns every vmcnt of the loop into 0 — for the
     // plain kernels too.  mrirt_render_brats_stream takes the generic kernel.)
     // ---- the asynchronous form (plain pipelined kernels: !SKIP): gathers the compiler does not count, one explicit wait ----
-    static constexpr int kTapLoads = NCH * (LAYOUT == 3 ? 2 : 8);
+    static constexpr int kTapLoads = NCH * (LAYOUT == 3 ? 2 : LAYOUT == 0 ? 4 : 8);
     static constexpr int kLoads = kTapLoads + (LABELS ? 2 : 0);          // vector-memory instructions issue_async() emits
     __device__ __forceinline__ void issue_async(const K1Args& a, const WaveGrid<LAYOUT>& wg) {
         CellOffsets k;
         if constexpr (LAYOUT == 4) k = flat_cell(wg.f, s.ix, s.iy, s.iz);
+        else if constexpr (LAYOUT == 0) { k.o = s.ix + s.iy * wg.g->sY + s.iz * wg.g->sZ; k.dx = 1u; k.dy = wg.g->sY; k.dz = wg.g->sZ; }
         else k = vec4_cell(*wg.g, s.ix, s.iy, s.iz);
 #pragma unroll
         for (int c = 0; c < NCH; ++c) taps[c].issue_async(wg.base(a.vol[a.chan[c]]), k);
@@ -193,6 +194,23 @@ struct Stage {
                                                  "+v"(q[4 % (2 * NCH)]), "+v"(q[5 % (2 * NCH)]), "+v"(q[6 % (2 * NCH)]), "+v"(q[7 % (2 * NCH)]) : "n"(YOUNGER));
 #pragma unroll
             for (int c = 0; c < NCH; ++c) { taps[c].q0 = __builtin_bit_cast(float4, q[2 * c]); taps[c].q1 = __builtin_bit_cast(float4, q[2 * c + 1]); }
+        } else if constexpr (LAYOUT == 0) {
+            // four register pairs per modality; an asm statement takes 30 operands, so the wait names the first two modalities'
+            // pairs and a second, empty statement (volatile: it stays behind the wait) names the rest
+            f32x2 q[4 * NCH];
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) q[4 * c + i] = taps[c].p[i];
+            constexpr int N = 4 * NCH;
+            if constexpr (NCH == 1) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]) : "n"(YOUNGER));
+            else asm volatile("s_waitcnt vmcnt(%8)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4 % N]), "+v"(q[5 % N]), "+v"(q[6 % N]), "+v"(q[7 % N]) : "n"(YOUNGER));
+            if constexpr (NCH == 3) asm volatile("" : "+v"(q[8 % N]), "+v"(q[9 % N]), "+v"(q[10 % N]), "+v"(q[11 % N]));
+            if constexpr (NCH == 4) asm volatile("" : "+v"(q[8 % N]), "+v"(q[9 % N]), "+v"(q[10 % N]), "+v"(q[11 % N]), "+v"(q[12 % N]), "+v"(q[13 % N]), "+v"(q[14 % N]), "+v"(q[15 % N]));
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) taps[c].p[i] = q[4 * c + i];
         } else {
             static_assert(LAYOUT == 3 || NCH == 1, "VG / VGA stages hold one modality");
             taps[0].template arrive<YOUNGER>();
@@ -559,15 +577,17 @@ static int launch_pipe(const K1Args& a, hipStream_t s) {
     // ... and drop the label state when no overlay is shown (STRICT only: FAST already fits)
     const bool overlays = a.showSeg != 0 || a.showPred != 0;
     // SKIP exists for the gamma == 1 STRICT kernels and for FAST; any other launch ignores the mask (still exact)
-    const bool skip = a.skipDist != nullptr;
+    // (LINEAR grids have no skipping kernels: mrirt_render_brats_skip never builds a map for them)
+    constexpr bool kHasSkip = LAYOUT != 0;
+    const bool skip = kHasSkip && a.skipDist != nullptr;
     if (STRICT && a.gamma == 1.0f && !overlays) {
-        if (skip) hipLaunchKernelGGL((brats_march_pipe_kernel<STRICT, LAYOUT, SHADE, NCH, STRICT, !STRICT, true>), grid, block, 0, s, a);
-        else      hipLaunchKernelGGL((brats_march_pipe_kernel<STRICT, LAYOUT, SHADE, NCH, STRICT, !STRICT, false>), grid, block, 0, s, a);
+        if constexpr (kHasSkip) { if (skip) { hipLaunchKernelGGL((brats_march_pipe_kernel<STRICT, LAYOUT, SHADE, NCH, STRICT, !STRICT, true>), grid, block, 0, s, a); MRIRT_HIP(hipGetLastError()); return MRIRT_OK; } }
+        hipLaunchKernelGGL((brats_march_pipe_kernel<STRICT, LAYOUT, SHADE, NCH, STRICT, !STRICT, false>), grid, block, 0, s, a);
     } else if (STRICT && a.gamma == 1.0f) {
-        if (skip) hipLaunchKernelGGL((brats_march_pipe_kernel<STRICT, LAYOUT, SHADE, NCH, STRICT, true, true>), grid, block, 0, s, a);
-        else      hipLaunchKernelGGL((brats_march_pipe_kernel<STRICT, LAYOUT, SHADE, NCH, STRICT, true, false>), grid, block, 0, s, a);
+        if constexpr (kHasSkip) { if (skip) { hipLaunchKernelGGL((brats_march_pipe_kernel<STRICT, LAYOUT, SHADE, NCH, STRICT, true, true>), grid, block, 0, s, a); MRIRT_HIP(hipGetLastError()); return MRIRT_OK; } }
+        hipLaunchKernelGGL((brats_march_pipe_kernel<STRICT, LAYOUT, SHADE, NCH, STRICT, true, false>), grid, block, 0, s, a);
     } else if (!STRICT && skip) {
-        hipLaunchKernelGGL((brats_march_pipe_kernel<STRICT, LAYOUT, SHADE, NCH, false, true, !STRICT>), grid, block, 0, s, a);
+        if constexpr (kHasSkip) hipLaunchKernelGGL((brats_march_pipe_kernel<STRICT, LAYOUT, SHADE, NCH, false, true, !STRICT>), grid, block, 0, s, a);
     } else {
         hipLaunchKernelGGL((brats_march_pipe_kernel<STRICT, LAYOUT, SHADE, NCH, false, true, false>), grid, block, 0, s, a);
     }
@@ -602,6 +622,17 @@ static int launch(const K1Args& a, bool pipeAsked, hipStream_t s) {
             }
         }
     }
+    if constexpr (LAYOUT == 0 && !SHADE) {            // LINEAR (the plain ABI): 4 register pairs per modality per stage -> up to four
+        if (pipe && a.skipDist == nullptr && (uint64_t)a.grid.X * a.grid.Y * a.grid.Z < (1ull << 30)) {    // 32-bit byte offsets
+            switch (a.nch) {
+                case 1: return launch_pipe<STRICT, 0, false, 1>(a, s);
+                case 2: return launch_pipe<STRICT, 0, false, 2>(a, s);
+                case 3: return launch_pipe<STRICT, 0, false, 3>(a, s);
+                case 4: return launch_pipe<STRICT, 0, false, 4>(a, s);
+                default: break;
+            }
+        }
+    }
     if constexpr (LAYOUT == 3) {                      // QUAD: 2 float4 per modality per stage -> up to four
         if (pipe && !a.grid.wide) {
             switch (a.nch) {
@@ -622,7 +653,7 @@ static int launch(const K1Args& a, bool pipeAsked, hipStream_t s) {
 template <bool STRICT>
 static int launch_layout(const K1Args& a, uint32_t layout, bool shade, bool pipe, hipStream_t s) {
     switch (layout) {
-        case MRIRT_LAYOUT_LINEAR: return shade ? launch<STRICT, 0, true>(a, false, s) : launch<STRICT, 0, false>(a, false, s);
+        case MRIRT_LAYOUT_LINEAR: return shade ? launch<STRICT, 0, true>(a, false, s) : launch<STRICT, 0, false>(a, pipe, s);
         case MRIRT_LAYOUT_BRICK:  return shade ? launch<STRICT, 1, true>(a, false, s) : launch<STRICT, 1, false>(a, false, s);
         case MRIRT_LAYOUT_VG:     return shade ? launch<STRICT, 2, true>(a, pipe, s) : launch<STRICT, 2, false>(a, pipe, s);
         case MRIRT_LAYOUT_QUAD:   return shade ? (int)MRIRT_ERR_LAYOUT : launch<STRICT, 3, false>(a, pipe, s);
