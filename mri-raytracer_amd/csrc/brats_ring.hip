@@ -271,6 +271,7 @@ __device__ __forceinline__ void march_ring(const K1Args& a, const RingGeom& gm, 
                 tailSlot += adv < R ? adv : adv % R;
                 tailSlot = tailSlot >= R ? tailSlot - R : tailSlot;
             }
+            if ((a.debugFlags & 2u) != 0u) qNext = tail + R;          // (kernelVariant bit 8: no loader at all — the consumer's side alone, timing only)
             if (qNext < tail + R) load_next();                        // two fills per round at most: rays advance <= 1.73 planes per step
             if (qNext < tail + R) load_next();                        // (longer steps: rounds in which nobody reads catch up)
         }

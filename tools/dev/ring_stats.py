@@ -23,5 +23,5 @@ def t(v, reps=20):
     run(v); torch.cuda.synchronize(); a = time.perf_counter()
     for _ in range(reps): mrirt.render_brats(p, [g], ext=dict(ext, kernelVariant=v))
     torch.cuda.synchronize(); return (time.perf_counter() - a) / reps * 1e3
-for name, v in (("default", 0), ("8x8 gather", 2), ("ring", 2048), ("ring R=3", 2048 | 4096), ("ring no fills", 2048 | 256), ("ring all fallback", 2048 | 1024)):
+for name, v in (("default", 0), ("8x8 gather", 2), ("ring", 2048), ("ring R=3", 2048 | 4096), ("ring no loader", 2048 | 256), ("ring R=3 no loader", 2048 | 4096 | 256), ("ring all fallback", 2048 | 1024)):
     print(f"{name:18s} {t(v):.3f} ms")
