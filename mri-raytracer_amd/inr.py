@@ -211,7 +211,7 @@ _C5_SCRATCH: dict = {}
 
 
 def render_brats_inr(params, intensities, net: PackedMLP, zmu, zsigma, labels=None, out=None, ext=None,
-                     return_aux: bool = False, chunk_steps: int = 32, one_pass: bool = False):
+                     return_aux: bool = False, chunk_steps: Optional[int] = None, one_pass: bool = False):
     """BASELINE config 5 (build-defined): K1 with the prediction overlay's label taken
     from the MLP evaluated AT every march sample (normalised sample coordinates + the four
     trilinear-sampled, z-scored modalities) instead of ``sampleLabel(gPreds)``.
@@ -223,7 +223,11 @@ def render_brats_inr(params, intensities, net: PackedMLP, zmu, zsigma, labels=No
 
     Default: ``mrirt_render_brats_inr`` — the march advances ``chunk_steps`` per pass and only rays that are still
     alive (t < t1, T > 0.01) have their next samples classified ("all live sample points"); no host
-    synchronisation inside the frame.  ``one_pass=True`` is the three-pass form over whole rays (count every
+    synchronisation inside the frame.  ``chunk_steps=None`` picks the pass length from the scene: where the intensity
+    channel alone cannot take any ray to T <= ert (intensityAlpha x box diagonal <= -ln ert — the reference viewer's whole
+    slider range) no sample is classified in vain whatever the pass length, and 64-step passes are the
+    faster ones (fewer launches and refinement rounds: 9.6 against 10.1 ms per frame on the config-5 scene); otherwise 32
+    (a terminating ray wastes at most 31 samples; 8.9 against 9.2 ms on the dense preset).  Any value gives the same bits.  ``one_pass=True`` is the three-pass form over whole rays (count every
     sample in [t0,t1) -> emit -> ONE batched forward -> composite with the class stream); both give the same
     bits, and ``return_aux`` of the one-pass form exposes the emitted inputs and classes for the layered tests.
     """
@@ -244,6 +248,10 @@ def render_brats_inr(params, intensities, net: PackedMLP, zmu, zsigma, labels=No
     vp = (C.c_void_p * 4)(*[C.c_void_p(t.data_ptr()) for t in vols])
     mu = (C.c_float * 4)(*[float(np.float32(v)) for v in zmu])
     sg = (C.c_float * 4)(*[float(np.float32(v)) for v in zsigma])
+    if chunk_steps is None:
+        diag = float(np.sqrt(sum((float(P.voxelSize[k]) * int(P.dims[k])) ** 2 for k in range(3))))
+        ert = float(E.ertThreshold) if int(E.ertOverride) else 0.01
+        chunk_steps = 64 if ert > 0.0 and float(P.intensityAlpha) * diag <= -np.log(ert) else 32
     if not one_pass:
         nbytes = int(lib.mrirt_brats_inr_scratch_bytes(C.byref(P), int(chunk_steps)))
         if nbytes <= 0:

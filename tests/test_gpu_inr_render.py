@@ -158,6 +158,14 @@ def test_c5_chunked_is_bit_identical_to_one_pass(setup, kind):
         assert a["live_samples"] == a0["live_samples"]
         assert a0["live_samples"] <= a["queries"] <= a0["queries"]
         seen.add(a["queries"])
+    # the default pass length follows the scene: 32 where intensity alone can terminate a ray (this dense preset), 64 where it
+    # cannot (the reference viewer's slider range) — same bits either way
+    img, a = inr.render_brats_inr(p, grids, net, s["zmu"], s["zsg"], labels=gl, return_aux=True)
+    assert a["chunk_steps"] == 32 and torch.equal(img, ref)
+    thin = dict(p, intensityAlpha=0.4)
+    ref_thin = inr.render_brats_inr(thin, grids, net, s["zmu"], s["zsg"], labels=gl, one_pass=True)
+    img, a = inr.render_brats_inr(thin, grids, net, s["zmu"], s["zsg"], labels=gl, return_aux=True)
+    assert a["chunk_steps"] == 64 and torch.equal(img, ref_thin)
     img1, a1 = inr.render_brats_inr(p, grids, net, s["zmu"], s["zsg"], labels=gl, return_aux=True, chunk_steps=1)
     assert a1["queries"] == a0["live_samples"], "one step per pass classifies exactly the live samples"
     assert len(seen) > 1
