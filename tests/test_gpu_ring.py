@@ -8,6 +8,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 RING = 2048          # kernelVariant bit 11
+RING3 = 2048 | 4096  # ... with three planes in the ring instead of four (bit 12)
 COUNT = 128          # bit 7: stats[1] = shaded + (reads outside a window | samples of waves that fell back)
 FALLBACK = 1024      # bit 10: every wave takes the gather march
 
@@ -49,6 +50,14 @@ def test_ring_random_cameras_match_the_oracle(env, seed):
     got, st = mrirt.render_brats(p, [g], ext=dict(ext, math="strict", layout="vga", kernelVariant=RING), stats=True)
     assert np.array_equal(got.cpu().numpy(), ref), (seed, dims, float(np.abs(got.cpu().numpy() - ref).max()))
     assert st["live_samples"] == aux["live_samples"] and st["shaded_samples"] == aux["shaded_samples"]
+    # three planes: lanes whose rays are out of phase wait more often, the samples they take are the same
+    got3, st3 = mrirt.render_brats(p, [g], ext=dict(ext, math="strict", layout="vga", kernelVariant=RING3), stats=True)
+    assert np.array_equal(got3.cpu().numpy(), ref) and st3 == st, (seed, dims)
+    # tile shards (compact buffers) and the half-float target go through the same kernel
+    if seed % 4 == 0:
+        tiled = mrirt.render_brats(p, [g], ext=dict(ext, math="strict", layout="vga", kernelVariant=RING, tileSize=64, tileRank=0, tileWorld=1))
+        plain = mrirt.render_brats(p, [g], ext=dict(ext, math="strict", layout="vga", kernelVariant=2, tileSize=64, tileRank=0, tileWorld=1))
+        assert np.array_equal(tiled.cpu().numpy(), plain.cpu().numpy())
     # fast math: the ring feeds the same blend as the gather kernels
     a = mrirt.render_brats(p, [g], ext=dict(ext, math="fast", layout="vga", kernelVariant=RING))
     b = mrirt.render_brats(p, [g], ext=dict(ext, math="fast", layout="vga", kernelVariant=2))
