@@ -7,6 +7,7 @@ model_load, predict_volume``: inr/interactive.ipynb cell 5, inr/viewer/brats_vie
   build_input(coords, intensities, fourier_freqs) -> (B, 3+6K+M)        model.py:21-23
   apply_mlp(params, x) -> logits                                        model.py:43-50
   predict_volume(params, case_data, fourier_freqs, chunk) -> (pred,seg) model.py:119-141
+  dice_score(pred, true, num_classes) / coverage_dice(pred, true)          model.py:144-161
   siren_apply(params, x, w0=30)                                         neumors_inr.ipynb:1165-1178
 
 ``params`` is the reference's list of ``{"W": [in,out], "b": [out]}`` (SIREN: dict ``l{i}`` ->
@@ -205,6 +206,50 @@ def predict_volume(params, case_data: Dict[str, Any], fourier_freqs: int, chunk:
     rc = _lib.lib().mrirt_inr_predict_volume(C.byref(net.desc), _ptr(mods), hwd, _ptr(pred), _stream_ptr(None))
     _lib.check(rc, "mrirt_inr_predict_volume")
     return pred, case_data["seg"]
+
+
+def _label_counts(pred, true, num_classes: int):
+    """Joint histogram of two label volumes: counts[p, t] for labels below ``num_classes`` (others in an overflow bin).
+    NumPy arrays stay on the host; torch tensors are counted where they live (one bincount, one small read-back)."""
+    n = int(num_classes)
+    if isinstance(pred, torch.Tensor) or isinstance(true, torch.Tensor):
+        dev = pred.device if isinstance(pred, torch.Tensor) else true.device
+        p = torch.as_tensor(pred, device=dev).reshape(-1).to(torch.int64)
+        t = torch.as_tensor(true, device=dev).reshape(-1).to(torch.int64)
+        if p.numel() != t.numel():
+            raise ValueError("dice: prediction and ground truth differ in size")
+        p = torch.where((p < 0) | (p >= n), torch.full_like(p, n), p)
+        t = torch.where((t < 0) | (t >= n), torch.full_like(t, n), t)
+        return torch.bincount(p * (n + 1) + t, minlength=(n + 1) * (n + 1)).reshape(n + 1, n + 1).cpu().numpy()
+    p = np.asarray(pred).reshape(-1).astype(np.int64)
+    t = np.asarray(true).reshape(-1).astype(np.int64)
+    if p.size != t.size:
+        raise ValueError("dice: prediction and ground truth differ in size")
+    p = np.where((p < 0) | (p >= n), n, p)
+    t = np.where((t < 0) | (t >= n), n, t)
+    return np.bincount(p * (n + 1) + t, minlength=(n + 1) * (n + 1)).reshape(n + 1, n + 1)
+
+
+def dice_score(pred, true, num_classes: int) -> Dict[int, float]:
+    """Per-class Dice of two label volumes — the third name inr/interactive.ipynb imports from inr.model next to
+    model_load and predict_volume (inr/inr/model.py:144-153): ``{c: (2 |P_c & T_c| + 1e-6) / (|P_c| + |T_c| + 1e-6)}``,
+    NaN for a class that occurs in neither volume.  Accepts what ``predict_volume`` returns (a device tensor) as is."""
+    h = _label_counts(pred, true, num_classes)
+    out: Dict[int, float] = {}
+    for c in range(int(num_classes)):
+        denom = int(h[c, :].sum()) + int(h[:, c].sum())
+        out[c] = (2 * int(h[c, c]) + 1e-6) / (denom + 1e-6) if denom > 0 else float("nan")
+    return out
+
+
+def coverage_dice(pred, true) -> float:
+    """Dice of the foregrounds (label > 0) of two label volumes (inr/inr/model.py:156-161); 0.0 when both are empty."""
+    pf = (pred > 0)
+    tf = (true > 0)
+    h = _label_counts(pf.to(torch.int64) if isinstance(pf, torch.Tensor) else np.asarray(pf, dtype=np.int64),
+                      tf.to(torch.int64) if isinstance(tf, torch.Tensor) else np.asarray(tf, dtype=np.int64), 2)
+    denom = int(h[1, :].sum()) + int(h[:, 1].sum())
+    return (2 * int(h[1, 1]) + 1e-6) / (denom + 1e-6) if denom > 0 else 0.0
 
 
 _C5_SCRATCH: dict = {}

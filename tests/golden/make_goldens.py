@@ -12,6 +12,9 @@ reference source never is.
       for the duration of the import (the four functions used are pure array expressions that
       read the same in either namespace; results are float64 where NumPy promotes, which the
       tests account for).  No reference code is copied or modified.
+  inr_metrics.npz                : dice_score / coverage_dice of the same model.py (the names the reference's
+      inr/interactive.ipynb imports next to model_load and predict_volume) on seeded label volumes,
+      incl. a class that is absent from both volumes (NaN) and an all-background pair (0.0).
   siren.npz                      : produced by the reference's own `siren_apply`.  That function lives
       in a notebook code cell (notebooks/neumors_inr.ipynb, "SECTION 7" cell), not in an importable
       module: the generator reads the cell's JSON, parses it with `ast`, takes the one `FunctionDef`
@@ -134,6 +137,28 @@ def _import_reference_model():
                 sys.modules[k] = v
 
 
+def metrics_goldens():
+    model = _import_reference_model()
+    rng = np.random.default_rng(77)
+    out = {}
+    cases = []
+    a = rng.integers(0, 4, (9, 8, 7)).astype(np.int16); b = rng.integers(0, 4, (9, 8, 7)).astype(np.int16)
+    cases.append((a, b, 4))
+    c = np.where(rng.random((6, 6, 6)) < 0.7, 0, rng.integers(1, 3, (6, 6, 6))).astype(np.int16)      # class 3 absent: NaN
+    d = np.where(rng.random((6, 6, 6)) < 0.6, 0, rng.integers(1, 3, (6, 6, 6))).astype(np.int16)
+    cases.append((c, d, 4))
+    cases.append((np.zeros((4, 4, 4), np.int16), np.zeros((4, 4, 4), np.int16), 3))                     # nothing but background
+    cases.append((a, a.copy(), 5))                                                                        # identical; class 4 absent
+    for i, (pred, true, nc) in enumerate(cases):
+        sc = model.dice_score(pred, true, nc)
+        out[f"c{i}_pred"], out[f"c{i}_true"], out[f"c{i}_nc"] = pred, true, np.int64(nc)
+        out[f"c{i}_dice"] = np.array([float(sc[k]) for k in range(nc)], dtype=np.float64)
+        out[f"c{i}_coverage"] = np.float64(model.coverage_dice(pred, true))
+    out["n"] = np.int64(len(cases))
+    np.savez_compressed(HERE / "inr_metrics.npz", **out)
+    print("metrics goldens:", len(cases), "cases")
+
+
 def inr_goldens():
     model = _import_reference_model()
     rng = np.random.default_rng(2024)
@@ -241,7 +266,11 @@ def render_goldens():
 if __name__ == "__main__":
     if not REF.exists():
         raise SystemExit(f"{REF} not found: goldens are generated in the build container only")
+    if len(sys.argv) > 1 and sys.argv[1] == "metrics":       # (only the newest fixture: the others stay byte-identical)
+        metrics_goldens()
+        raise SystemExit(0)
     camera_goldens()
     inr_goldens()
+    metrics_goldens()
     siren_goldens()
     render_goldens()

@@ -174,3 +174,22 @@ def test_two_restatements_agree_bitwise(seed):
     if H >= 4:
         band = oracle_c.brats_main(p, vols, lab, np.roll(lab, 3), ext, rows=(1, H - 1))
         assert np.array_equal(band, b[1:H - 1], equal_nan=True)
+
+
+def test_dice_scores_match_the_reference(golden_dir):
+    """inr.dice_score / inr.coverage_dice (the names inr/interactive.ipynb imports from inr.model) against values produced by
+    the reference's own model.py (tests/golden/make_goldens.py::metrics_goldens): NumPy inputs and torch tensors, a class
+    absent from both volumes (NaN), an all-background pair (coverage 0.0)."""
+    import torch
+    from mrirt import inr
+    g = np.load(golden_dir / "inr_metrics.npz")
+    for i in range(int(g["n"])):
+        pred, true, nc = g[f"c{i}_pred"], g[f"c{i}_true"], int(g[f"c{i}_nc"])
+        want = g[f"c{i}_dice"]
+        for p, t in ((pred, true), (torch.from_numpy(pred), torch.from_numpy(true)), (torch.from_numpy(pred), true)):
+            got = inr.dice_score(p, t, nc)
+            assert sorted(got) == list(range(nc))
+            np.testing.assert_array_equal(np.array([got[c] for c in range(nc)]), want)      # same expression, same bits (NaN == NaN here)
+            assert inr.coverage_dice(p, t) == float(g[f"c{i}_coverage"])
+    with pytest.raises(ValueError):
+        inr.dice_score(np.zeros(5, np.int16), np.zeros(6, np.int16), 2)
