@@ -292,7 +292,7 @@ def k1_reference_path(dev, frames=20):
     n, image, steps = 256, 512, 256
     vols = [synth.synth_volume(n, 1234 + m, phase=0.3 * m) for m in range(4)]
     gv = [mrirt.upload_grid(v, (n, n, n), "quad") for v in vols]
-    gl = mrirt.upload_grid(synth.synth_labels(n), (n, n, n), "brick")
+    gl = mrirt.upload_label_cells(synth.synth_labels(n), None, (n, n, n))      # the seg overlay as label cells: one 8-byte gather at the cell's own offset (what the shim binds)
     p = synth.brats_scene(n, image, steps, channels=4, show_seg=True, intensity_alpha=0.4)
     out = torch.empty((image, image, 4), dtype=torch.float32, device=dev)
     ext = dict(layout="quad", math="strict")
@@ -310,7 +310,7 @@ def k1_reference_path(dev, frames=20):
     traffic, on_chip, note = measured_traffic(f"C2:{n}:{image}:{steps}:quad:strict:4ch+seg")
     hbm = traffic if traffic is not None else compulsory
     return {"workload": f"C2: {n}^3 x 4 modalities + seg overlay, {image}x{image} px, {steps} steps/ray, perspective, no shading (the "
-                        "reference's brats_main as the viewer runs it); QUAD voxels, STRICT math, bit-identical to the oracle",
+                        "reference's brats_main as the viewer runs it); QUAD voxels + label cells, STRICT math, bit-identical to the oracle",
             "value": round(live / (ms * 1e-3) / 1e6, 1), "unit": "Msamples/s", "ms_per_frame": round(ms, 4), "dtype": "f32",
             "live_samples_per_frame": live, "nominal_samples_per_frame": image * image * steps,
             "roofline": {"bound": "hbm", "achieved": round(hbm / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

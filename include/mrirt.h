@@ -79,7 +79,16 @@ typedef enum MrirtLayout {
      *       entered through; the kernel reads the copy whose bricks are flat in that direction (chosen per packet),
      *       so a gather touches about half the cache lines of the 2x2x2 bricks.  Same bits as VG; 3x the memory
      *       (6 GiB for a 512^3 channel: sized for 288 GB of HBM).  mrirt_vga_elems / mrirt_build_vec4_grid.        */
-    MRIRT_LAYOUT_VGA = 4
+    MRIRT_LAYOUT_VGA = 4,
+    /* Label grids only (labelLayout), with QUAD intensity grids: BOTH overlays' nearest labels per CELL.  sampleLabel's
+     * rounded voxel (brats_rt.slang:78-83) is always one of the eight corners of the cell sampleLinear blends
+     * (round(clamp(q, 0, d-1)) - floor(clamp(q, 0, d-1.001)) is 0 or 1 per axis), and the shader draws labels 1..7 only
+     * (:145,156), so one 8-byte element per voxel holds what a sample needs of both grids: .x = the ground-truth labels of
+     * the cell's corners as eight nibbles (corner (dx,dy,dz) in bits 4 (dx + 2 dy + 4 dz) .., neighbours clamped to the grid,
+     * labels >= 8 stored as 8), .y = the prediction's likewise; elements in the QUAD grid's order (mrirt_vec4_elems).  A
+     * sample then takes ONE 8-byte gather at the offset its intensity taps already have instead of two nearest-voxel
+     * gathers.  mrirt_build_label_cells makes it; `labels` points at it, `preds` is ignored.                              */
+    MRIRT_LAYOUT_LABCELL = 5
 } MrirtLayout;
 
 typedef enum MrirtMath {
@@ -103,7 +112,7 @@ typedef struct MrirtRenderExt {
     uint32_t math;              /* MrirtMath                                                   */
     uint32_t outFormat;         /* MrirtOutFormat                                              */
     uint32_t layout;            /* MrirtLayout of ALL bound fp32 intensity grids               */
-    uint32_t labelLayout;       /* MrirtLayout (LINEAR or BRICK) of the labels / preds grids   */
+    uint32_t labelLayout;       /* MrirtLayout (LINEAR, BRICK or LABCELL) of the labels / preds grids */
     /* Image-tile sharding (one process per GPU).  tileSize == 0: whole image into
      * out[y*pitch + x].  Otherwise this call renders the tiles t with t % tileWorld ==
      * tileRank (t = ty*tilesX + tx, tiles of tileSize^2 pixels) into a COMPACT buffer
@@ -176,6 +185,9 @@ int64_t mrirt_vec4_elems(const uint32_t dims[3]);
 int64_t mrirt_vga_elems(const uint32_t dims[3]);
 /* linear fp32 (x fastest) -> VG, QUAD or VGA float4 grid (layout = MRIRT_LAYOUT_VG / _QUAD / _VGA). */
 int mrirt_build_vec4_grid(const float* linear, void* vec4_grid, const uint32_t dims[3], uint32_t layout, void* stream);
+/* linear uint32 label grids (the reference's gLabels / gPreds uploads, brats_viewer.py:71-73; either may be NULL = no labels)
+ * -> the MRIRT_LAYOUT_LABCELL grid: mrirt_vec4_elems(dims) elements of 8 bytes, device. */
+int mrirt_build_label_cells(const uint32_t* seg_linear, const uint32_t* pred_linear, const uint32_t dims[3], void* cells, void* stream);
 /* BC4 / RGTC1-unorm slices (8-byte blocks, [depth][ceil(h/4)][ceil(w/4)], device, 8-byte aligned) -> u8 voxels
  * [depth][height][width]: the decode scripts/volumeRendering/app.py:200-250 does on the host. */
 int mrirt_bc4_decode(const void* blocks, uint32_t width, uint32_t height, uint32_t depth, uint8_t* out_u8, void* stream);

@@ -37,6 +37,7 @@ struct K1Args {
     const void* vol[4];
     const uint32_t* labels;
     const uint32_t* preds;
+    const uint2* labCell;         // MRIRT_LAYOUT_LABCELL: both overlays' corner labels per cell (QUAD grids); labels / preds unused then
     const int16_t* classStream;   // C5: prediction label of sample k of ray p at classStream[rayOffsets[p] + k]
     const int64_t* rayOffsets;
     const uint8_t* skipDist;      // exact empty-space skipping: byte per 8^3 macro cell; 0 = may contribute, r >= 1 = this cell
@@ -290,6 +291,12 @@ __device__ __forceinline__ void async_load_pair(f32x2& dst, const void* __restri
     asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(t) : "v"(byteOff), "s"(base));
     dst = t;
 }
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void async_load_words2(u32x2& dst, const void* __restrict__ base, uint32_t byteOff) {     // (label cells)
+    u32x2 t;
+    asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(t) : "v"(byteOff), "s"(base));
+    dst = t;
+}
 template <> struct Taps<0, false> {
     f32x2 p[4];                                      // (x0, x1) at (y0, z0), (y1, z0), (y0, z1), (y1, z1)
     template <bool WIDE>
@@ -331,12 +338,30 @@ struct RayState { float C0, C1, C2, T; uint32_t nLive, nShaded; };
 
 // the two nearest-label gathers of a sample (issued with the intensity gathers, consumed in composite)
 struct Labels { uint32_t seg, pred; };
+// LABCELL: which nibble of the cell's label words is sampleLabel's voxel — round(clamp(q, 0, d-1)) is the cell's base index
+// or one more, per axis (include/mrirt.h) — as a shift count
+__device__ __forceinline__ uint32_t label_corner_shift(const K1Args& a, const Cell& s) {
+    const uint32_t rx = (uint32_t)roundf(clampf(s.q[0], 0.0f, a.hiLab[0])) - s.ix;
+    const uint32_t ry = (uint32_t)roundf(clampf(s.q[1], 0.0f, a.hiLab[1])) - s.iy;
+    const uint32_t rz = (uint32_t)roundf(clampf(s.q[2], 0.0f, a.hiLab[2])) - s.iz;
+    return (rx + 2u * ry + 4u * rz) << 2;
+}
+__device__ __forceinline__ void labels_from_cell(const K1Args& a, uint32_t segWord, uint32_t predWord, uint32_t shift, Labels& l) {
+    l.seg = a.showSeg != 0 ? (segWord >> shift) & 15u : 0u;
+    l.pred = a.showPred != 0 ? (predWord >> shift) & 15u : 0u;
+}
 __device__ __forceinline__ void fetch_labels(const K1Args& a, const Cell& s, Labels& l) {
+    if (a.labCell != nullptr) {                                                      // uniform
+        const uint2 w = a.labCell[AddrVec4::ox(a.grid, s.ix) + AddrVec4::oy(a.grid, s.iy) + AddrVec4::oz(a.grid, s.iz)];
+        labels_from_cell(a, w.x, w.y, label_corner_shift(a, s), l);
+        return;
+    }
     l.seg = a.showSeg != 0 ? sample_label(a.labels, a.lab, s.q, a.hiLab) : 0u;      // :144
     l.pred = a.showPred != 0 ? sample_label(a.preds, a.lab, s.q, a.hiLab) : 0u;    // :155
 }
 // ... and with the prediction label taken from C5's class stream (one class per sample of the ray; generic kernel only)
 __device__ __forceinline__ void fetch_labels_stream(const K1Args& a, const Cell& s, Labels& l, int64_t streamRow) {
+    if (a.labCell != nullptr && a.classStream == nullptr) { fetch_labels(a, s, l); return; }
     l.seg = a.showSeg != 0 ? sample_label(a.labels, a.lab, s.q, a.hiLab) : 0u;
     if (a.showPred == 0) l.pred = 0u;
     else if (a.classStream != nullptr) l.pred = (uint32_t)(uint16_t)a.classStream[streamRow];

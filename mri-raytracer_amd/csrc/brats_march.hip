@@ -144,11 +144,16 @@ struct MapWindow {
     }
 };
 
-template <int LAYOUT, bool SHADE, int NCH, bool LABELS, bool SKIP>
+// CELLS (QUAD grids): the labels come from the MRIRT_LAYOUT_LABCELL grid — ONE 8-byte gather at the cell's own offset for both
+// overlays instead of two nearest-voxel gathers (the plain pipelined kernel counts its loads at compile time, hence a template axis;
+// the skipping and generic kernels take the same grid through fetch_labels at run time).
+template <int LAYOUT, bool SHADE, int NCH, bool LABELS, bool SKIP, bool CELLS = false>
 struct Stage {
     Cell s;
     Taps<LAYOUT, SHADE> taps[NCH];
     Labels lb;
+    u32x2 cw;                        // CELLS: the cell's two label words, in flight with the taps
+    uint32_t csh;                    // ... and which nibble of them is this sample's
     uint32_t dist;                   // SKIP: the map byte of the sample's macro cell (0 = fetch and composite)
     bool empty;
     __device__ __forceinline__ void classify(uint32_t d) { dist = d; empty = SKIP && d != 0u; }
@@ -157,7 +162,7 @@ struct Stage {
     // plain kernels too.  mrirt_render_brats_stream takes the generic kernel.)
     // ---- the asynchronous form (plain pipelined kernels: !SKIP): gathers the compiler does not count, one explicit wait ----
     static constexpr int kTapLoads = NCH * (LAYOUT == 3 ? 2 : LAYOUT == 0 ? 4 : 8);
-    static constexpr int kLoads = kTapLoads + (LABELS ? 2 : 0);          // vector-memory instructions issue_async() emits
+    static constexpr int kLoads = kTapLoads + (LABELS ? (CELLS ? 1 : 2) : 0);   // vector-memory instructions issue_async() emits
     __device__ __forceinline__ void issue_async(const K1Args& a, const WaveGrid<LAYOUT>& wg) {
         CellOffsets k;
         if constexpr (LAYOUT == 4) k = flat_cell(wg.f, s.ix, s.iy, s.iz);
@@ -165,7 +170,11 @@ struct Stage {
         else k = vec4_cell(*wg.g, s.ix, s.iy, s.iz);
 #pragma unroll
         for (int c = 0; c < NCH; ++c) taps[c].issue_async(wg.base(a.vol[a.chan[c]]), k);
-        if constexpr (LABELS) {
+        if constexpr (LABELS && CELLS) {
+            static_assert(LAYOUT == 3, "label cells are stored in the QUAD grid's element order");
+            async_load_words2(cw, a.labCell, k.o << 3);
+            csh = label_corner_shift(a, s);
+        } else if constexpr (LABELS) {
             // both label gathers are ALWAYS issued (a hidden overlay reads word 0 of the first modality and is masked in
             // arrive()): the count the wait rests on must not depend on the overlays
             const uint32_t ix = (uint32_t)roundf(clampf(s.q[0], 0.0f, a.hiLab[0]));
@@ -215,7 +224,11 @@ struct Stage {
             static_assert(LAYOUT == 3 || NCH == 1, "VG / VGA stages hold one modality");
             taps[0].template arrive<YOUNGER>();
         }
-        if constexpr (LABELS) {
+        if constexpr (LABELS && CELLS) {
+            u32x2 w = cw;
+            asm volatile("" : "+v"(w));                                     // (the label words arrived with the taps: same wait)
+            labels_from_cell(a, w.x, w.y, csh, lb);
+        } else if constexpr (LABELS) {
             uint32_t ls = lb.seg, lp = lb.pred;
             asm volatile("" : "+v"(ls), "+v"(lp));                          // (the label words arrived with the taps: same wait)
             lb.seg = a.showSeg != 0 ? ls : 0u;
@@ -342,7 +355,7 @@ __device__ __forceinline__ void march_skip(const K1Args& a, const WaveGrid<LAYOU
     }
 }
 
-template <bool STRICT, int LAYOUT, bool SHADE, int NCH, bool GAMMA1, bool LABELS, bool SKIP>
+template <bool STRICT, int LAYOUT, bool SHADE, int NCH, bool GAMMA1, bool LABELS, bool SKIP, bool CELLS = false>
 __global__ __launch_bounds__(256, (LABELS || SKIP) ? 3 : 4) void brats_march_pipe_kernel(const K1Args a) {
     __shared__ float4 lutShared[LABELS ? 16 : 1];
     const float4* lutS = nullptr;
@@ -365,8 +378,8 @@ __global__ __launch_bounds__(256, (LABELS || SKIP) ? 3 : 4) void brats_march_pip
         // every trip, i.e. it waited for A's gathers BEFORE issuing B's, and half of the overlap was gone: seen in the ISA of
         // every pipelined kernel.  In this order every wait sits in front of the blend that needs it and nothing else.)
         // t runs exactly as in the shader: t_{k+1} = t_k + stepSize (brats_rt.slang:164), one running fp32 sum.
-        Stage<LAYOUT, SHADE, NCH, LABELS, SKIP> A, B;
-        constexpr int kN = Stage<LAYOUT, SHADE, NCH, LABELS, SKIP>::kLoads;
+        Stage<LAYOUT, SHADE, NCH, LABELS, SKIP, CELLS> A, B;
+        constexpr int kN = Stage<LAYOUT, SHADE, NCH, LABELS, SKIP, CELLS>::kLoads;
         // ONE static issue site and ONE wait per stage: a second site (a prologue that primes the stages) makes the stage's
         // registers a phi at the loop header, and the copies the allocator resolves phis with would read gather destinations
         // that are still in flight (tools/check_async_loads.py found exactly that).  So the pipeline fills inside the loop:
@@ -580,6 +593,14 @@ static int launch_pipe(const K1Args& a, hipStream_t s) {
     // (LINEAR grids have no skipping kernels: mrirt_render_brats_skip never builds a map for them)
     constexpr bool kHasSkip = LAYOUT != 0;
     const bool skip = kHasSkip && a.skipDist != nullptr;
+    if constexpr (LAYOUT == 3) {
+        if (a.labCell != nullptr && overlays && !skip) {                 // label cells: the plain pipelined kernel with one label gather
+            if (STRICT && a.gamma == 1.0f) hipLaunchKernelGGL((brats_march_pipe_kernel<STRICT, LAYOUT, SHADE, NCH, STRICT, true, false, true>), grid, block, 0, s, a);
+            else                           hipLaunchKernelGGL((brats_march_pipe_kernel<STRICT, LAYOUT, SHADE, NCH, false, true, false, true>), grid, block, 0, s, a);
+            MRIRT_HIP(hipGetLastError());
+            return MRIRT_OK;
+        }
+    }
     if (STRICT && a.gamma == 1.0f && !overlays) {
         if constexpr (kHasSkip) { if (skip) { hipLaunchKernelGGL((brats_march_pipe_kernel<STRICT, LAYOUT, SHADE, NCH, STRICT, !STRICT, true>), grid, block, 0, s, a); MRIRT_HIP(hipGetLastError()); return MRIRT_OK; } }
         hipLaunchKernelGGL((brats_march_pipe_kernel<STRICT, LAYOUT, SHADE, NCH, STRICT, !STRICT, false>), grid, block, 0, s, a);
@@ -931,15 +952,18 @@ static int prepare(const MrirtBratsParams* p, const MrirtRenderExt* ext, const v
     const uint32_t math = ext ? ext->math : (uint32_t)MRIRT_MATH_STRICT;
     const uint32_t fmt = ext ? ext->outFormat : (uint32_t)MRIRT_OUT_RGBA32F;
     const uint32_t variant = ext ? ext->kernelVariant : 0u;
-    if (layout > MRIRT_LAYOUT_VGA || labLayout > MRIRT_LAYOUT_BRICK || math > MRIRT_MATH_FAST || fmt > MRIRT_OUT_RGBA16F)
+    const bool labCells = labLayout == MRIRT_LAYOUT_LABCELL;              // both overlays' corner labels per cell: QUAD grids only
+    if (layout > MRIRT_LAYOUT_VGA || (labLayout > MRIRT_LAYOUT_BRICK && !labCells) || math > MRIRT_MATH_FAST || fmt > MRIRT_OUT_RGBA16F)
         return MRIRT_ERR_LAYOUT;
+    if (labCells && layout != MRIRT_LAYOUT_QUAD) return MRIRT_ERR_LAYOUT;
+    if (labCells && mrirt_vec4_elems(p->dims) >= (int64_t)1 << 29) return MRIRT_ERR_DIMS;      // 32-bit byte offsets of 8-byte elements
     if (layout == MRIRT_LAYOUT_VGA)
         for (int c = 0; c < 3; ++c) if (vga_copy_elems(p->dims, c) >= (1ull << 28)) return MRIRT_ERR_DIMS;   // 32-bit byte offsets per copy
     if (mrirt_brick_elems(p->dims) >= (int64_t)1 << 32 || mrirt_vec4_elems(p->dims) >= (int64_t)1 << 32)
         return MRIRT_ERR_DIMS;                                           // 32-bit element offsets
     if (needVolumes) {
         for (int m = 0; m < 4; ++m) if (p->volEnabled[m] != 0 && !vol[m]) return MRIRT_ERR_NULL;
-        if (p->showSeg != 0 && !labels) return MRIRT_ERR_NULL;
+        if ((p->showSeg != 0 || (labCells && p->showPred != 0)) && !labels) return MRIRT_ERR_NULL;
     }
     {
         // The march is `while (t < t1 && T > ert) { ...; t += stepSize; }` (brats_rt.slang:117-165) and the C5
@@ -991,7 +1015,7 @@ static int prepare(const MrirtBratsParams* p, const MrirtRenderExt* ext, const v
     if (rc != MRIRT_OK) return rc;
     fill_grid_dims(a.grid, p->dims, layout == MRIRT_LAYOUT_VGA ? (uint32_t)MRIRT_LAYOUT_VG : layout);
     fill_vga_dims(a.vga, p->dims);
-    fill_label_addr(a.lab, p->dims, labLayout);
+    fill_label_addr(a.lab, p->dims, labCells ? (uint32_t)MRIRT_LAYOUT_LINEAR : labLayout);
     for (int k = 0; k < 3; ++k) {
         a.bmin[k] = p->volMin[k];
         a.bmax[k] = p->volMin[k] + p->voxelSize[k] * (float)p->dims[k];
@@ -1030,8 +1054,9 @@ static int prepare(const MrirtBratsParams* p, const MrirtRenderExt* ext, const v
     a.specPow2 = ext ? ext->specPow2 : 0u;
     a.ert = (ext && ext->ertOverride) ? ext->ertThreshold : 0.01f;   // brats_rt.slang:117
     a.half = fmt == MRIRT_OUT_RGBA16F ? 1u : 0u;
-    a.labels = static_cast<const uint32_t*>(labels);
-    a.preds = static_cast<const uint32_t*>(preds);
+    a.labels = labCells ? nullptr : static_cast<const uint32_t*>(labels);
+    a.preds = labCells ? nullptr : static_cast<const uint32_t*>(preds);
+    a.labCell = labCells ? static_cast<const uint2*>(labels) : nullptr;
     a.classStream = nullptr; a.rayOffsets = nullptr;
     a.skipDist = nullptr; a.mX = a.mXY = a.mY = a.mZ = 0; a.leap = 0;
     fill_exp_consts(a.ec);
@@ -1131,7 +1156,7 @@ extern "C" int mrirt_render_brats_ex(const MrirtBratsParams* p, const MrirtRende
     Prepared cfg;
     int rc = prepare(p, ext, vol, labels, preds, true, pitch_px, a, cfg);
     if (rc != MRIRT_OK) return rc;
-    if (p->showPred != 0 && !preds) return MRIRT_ERR_NULL;
+    if (p->showPred != 0 && !preds && a.labCell == nullptr) return MRIRT_ERR_NULL;
     a.out = out_rgba;
     a.stats = stats_dev;
     if (a.map.numBlocks == 0) return MRIRT_OK;   // a rank that owns no tile
@@ -1152,7 +1177,7 @@ extern "C" int mrirt_render_brats_skip(const MrirtBratsParams* p, const MrirtRen
     Prepared cfg;
     int rc = prepare(p, ext, vol, labels, preds, true, pitch_px, a, cfg);
     if (rc != MRIRT_OK) return rc;
-    if (p->showPred != 0 && !preds) return MRIRT_ERR_NULL;
+    if (p->showPred != 0 && !preds && a.labCell == nullptr) return MRIRT_ERR_NULL;
     a.out = out_rgba;
     a.stats = stats_dev;
     if (a.map.numBlocks == 0) return MRIRT_OK;
@@ -1230,6 +1255,7 @@ extern "C" int mrirt_render_brats_stream(const MrirtBratsParams* p, const MrirtR
     Prepared cfg;
     int rc = prepare(p, ext, vol, labels, nullptr, true, pitch_px, a, cfg);
     if (rc != MRIRT_OK) return rc;
+    if (a.labCell != nullptr) return MRIRT_ERR_LAYOUT;           // (the class stream replaces gPreds; label cells carry both grids)
     if (p->showPred == 0) return MRIRT_ERR_ARG;
     a.classStream = classes; a.rayOffsets = offsets;
     a.out = out_rgba; a.stats = stats_dev;
@@ -1377,6 +1403,7 @@ extern "C" int mrirt_render_brats_inr(const MrirtBratsParams* p, const MrirtRend
     Prepared cfg;
     int rc = prepare(p, ext, vol, labels, nullptr, true, pitch_px, a, cfg);
     if (rc != MRIRT_OK) return rc;
+    if (a.labCell != nullptr) return MRIRT_ERR_LAYOUT;           // the C5 passes read the ground-truth grid themselves (LINEAR / BRICK)
     if (p->showPred == 0) return MRIRT_ERR_ARG;
     C5Scratch sc;
     rc = c5_carve(p, chunk_steps, scratch, sc);

@@ -266,6 +266,45 @@ extern "C" int mrirt_build_vec4_grid(const float* linear, void* vec4_grid, const
     return MRIRT_OK;
 }
 
+// LABCELL (include/mrirt.h): per voxel = cell base, the nearest-label candidates of BOTH label grids: the labels of the cell's
+// eight corners as nibbles (corner (dx,dy,dz) at bits 4 (dx + 2 dy + 4 dz), neighbours clamped, labels >= 8 -> 8: the shader
+// draws 1..7 only), .x ground truth, .y prediction; elements in the QUAD grid's order.
+__global__ __launch_bounds__(256) void label_cells_kernel(const uint32_t* __restrict__ seg, const uint32_t* __restrict__ pred,
+                                                          uint2* __restrict__ dst, uint32_t X, uint32_t Y, uint32_t Z,
+                                                          uint32_t nbx, uint32_t nby, uint64_t total) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;      // element index in dst (the vec4 grids' order)
+    if (e >= total) return;
+    const uint32_t in = (uint32_t)(e & 7u);
+    const uint64_t b = e >> 3;
+    const uint32_t bx = (uint32_t)(b % nbx), by = (uint32_t)((b / nbx) % nby), bz = (uint32_t)(b / ((uint64_t)nbx * nby));
+    const uint32_t x = bx * 2 + (in & 1u), y = by * 2 + ((in >> 1) & 1u), z = bz * 2 + (in >> 2);
+    uint2 o = make_uint2(0u, 0u);
+    if (x < X && y < Y && z < Z) {
+        const uint64_t sY = X, sZ = (uint64_t)X * Y;
+#pragma unroll
+        for (uint32_t c = 0; c < 8; ++c) {
+            const uint32_t xx = min(x + (c & 1u), X - 1), yy = min(y + ((c >> 1) & 1u), Y - 1), zz = min(z + (c >> 2), Z - 1);
+            const uint64_t i = xx + yy * sY + zz * sZ;
+            if (seg != nullptr)  o.x |= min(seg[i], 8u) << (4u * c);
+            if (pred != nullptr) o.y |= min(pred[i], 8u) << (4u * c);
+        }
+    }
+    dst[e] = o;
+}
+
+extern "C" int mrirt_build_label_cells(const uint32_t* seg_linear, const uint32_t* pred_linear, const uint32_t dims[3],
+                                       void* cells, void* stream) {
+    if (!cells || !dims) return MRIRT_ERR_NULL;
+    for (int k = 0; k < 3; ++k) if (dims[k] < 2) return MRIRT_ERR_DIMS;
+    const uint32_t nbx = (dims[0] + 1) / 2, nby = (dims[1] + 1) / 2;
+    const uint64_t total = (uint64_t)mrirt_vec4_elems(dims);
+    if (total >= (1ull << 29)) return MRIRT_ERR_DIMS;                        // 32-bit byte offsets of 8-byte elements
+    hipLaunchKernelGGL(label_cells_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       seg_linear, pred_linear, static_cast<uint2*>(cells), dims[0], dims[1], dims[2], nbx, nby, total);
+    MRIRT_HIP(hipGetLastError());
+    return MRIRT_OK;
+}
+
 extern "C" int64_t mrirt_macro_cells(const uint32_t dims[3]) {
     if (!dims) return 0;
     return (int64_t)((dims[0] + 7) / 8) * ((dims[1] + 7) / 8) * ((dims[2] + 7) / 8);

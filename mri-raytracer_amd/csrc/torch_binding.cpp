@@ -70,6 +70,7 @@ int64_t grid_need(const uint32_t dims[3], uint32_t layout) {
         case MRIRT_LAYOUT_LINEAR: return (int64_t)dims[0] * dims[1] * dims[2];
         case MRIRT_LAYOUT_BRICK:  return mrirt_brick_elems(dims);
         case MRIRT_LAYOUT_VGA:    return 4 * mrirt_vga_elems(dims);
+        case MRIRT_LAYOUT_LABCELL: return 2 * mrirt_vec4_elems(dims);      // 8-byte elements, counted in int32
         default:                  return 4 * mrirt_vec4_elems(dims);
     }
 }
@@ -94,7 +95,9 @@ Tensor render_brats(const Tensor& params, const Tensor& ext, const OptTensor& vo
     const void* lab = dev_ptr(labels, at::kInt, "gLabels");
     const void* prd = dev_ptr(preds, at::kInt, "gPreds");
     TORCH_CHECK_VALUE(P.showSeg == 0 || (labels.has_value() && labels->numel() >= lneed), "showSeg is set but gLabels is missing or too small");
-    TORCH_CHECK_VALUE(P.showPred == 0 || (preds.has_value() && preds->numel() >= lneed), "showPred is set but gPreds is missing or too small");
+    const bool cells = E.labelLayout == MRIRT_LAYOUT_LABCELL;          // gLabels carries both grids, gPreds is ignored
+    const OptTensor& predSrc = cells ? labels : preds;
+    TORCH_CHECK_VALUE(P.showPred == 0 || (predSrc.has_value() && predSrc->numel() >= lneed), "showPred is set but gPreds (or the label-cell grid) is missing or too small");
     same_device(dev, labels, "gLabels");
     same_device(dev, preds, "gPreds");
     DeviceGuard guard(*dev);

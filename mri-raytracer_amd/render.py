@@ -54,6 +54,7 @@ class Grid:
     layout: str = "linear"        # "linear" | "brick" | "vg" | "quad" | "vga"
     macro: Optional[torch.Tensor] = None   # per 8^3 macro cell: fp32 upper bound (intensities) / any-label word
                                            # (label grids) — what exact empty-space skipping tests (skip=True)
+    macro2: Optional[torch.Tensor] = None  # "labcell" grids: the prediction grid's summary (macro = the ground truth's)
 
     @property
     def nbytes(self) -> int:
@@ -114,6 +115,31 @@ def upload_grid(linear: ArrayLike, dims: Sequence[int], layout: str = "brick", s
     _lib.check(_lib.lib().mrirt_brick_grid(_ptr(t), _ptr(out), d, t.element_size(), _stream_ptr(stream)),
                "mrirt_brick_grid")
     return Grid(out, dims, "brick", macro)
+
+
+def upload_label_cells(seg: Optional[ArrayLike], pred: Optional[ArrayLike], dims: Sequence[int], stream=None, macro: bool = True) -> Grid:
+    """Both label grids of the viewer (gLabels, gPreds: linear uint32, either may be None) as ONE "labcell" grid for QUAD
+    intensity grids: per cell the corner labels of both as nibbles, in the QUAD grid's element order (include/mrirt.h,
+    MRIRT_LAYOUT_LABCELL).  sampleLabel's rounded voxel is always one of the sample's cell corners and the shader draws labels
+    1..7 only, so a sample takes one 8-byte gather at the offset its intensity taps already have instead of two nearest-voxel
+    gathers — same bits.  Bind it as ``labels=`` (``preds`` is then ignored)."""
+    dev = _require_gpu()
+    dims = tuple(int(v) for v in dims)
+    n = dims[0] * dims[1] * dims[2]
+    lin, macros = [], []
+    for g, what in ((seg, "seg"), (pred, "pred")):
+        if g is None:
+            lin.append(None); macros.append(None)
+            continue
+        t = _as_device_tensor(g, torch.int32, dev, what)
+        if t.numel() != n:
+            raise ValueError(f"{what} has {t.numel()} voxels, dims {dims} need {n}")
+        lin.append(t)
+        macros.append(_build_macro(t, dims, stream) if macro else None)
+    out = torch.empty(2 * vec4_elems(dims), dtype=torch.int32, device=dev)
+    d = (C.c_uint32 * 3)(*dims)
+    _lib.check(_lib.lib().mrirt_build_label_cells(_ptr(lin[0]), _ptr(lin[1]), d, _ptr(out), _stream_ptr(stream)), "mrirt_build_label_cells")
+    return Grid(out, dims, "labcell", macros[0], macros[1])
 
 
 def _build_macro(t: torch.Tensor, dims, stream=None) -> Optional[torch.Tensor]:
@@ -194,7 +220,7 @@ def _bind_brats(params, intensities, labels, preds, ext, dev, pred_stream: bool 
     if lgrids and "labelLayout" not in e:
         e["labelLayout"] = lgrids[0].layout
     E = render_ext(e)
-    names = {v: k for k, v in (("linear", 0), ("brick", 1), ("vg", 2), ("quad", 3), ("vga", 4))}
+    names = {v: k for k, v in (("linear", 0), ("brick", 1), ("vg", 2), ("quad", 3), ("vga", 4), ("labcell", 5))}
     lay, lab_lay = names[E.layout], names[E.labelLayout]
     for g, want in [(g, lay) for g in vgrids] + [(g, lab_lay) for g in lgrids]:
         if g.layout != want:
@@ -204,7 +230,9 @@ def _bind_brats(params, intensities, labels, preds, ext, dev, pred_stream: bool 
     dims = tuple(int(v) for v in P.dims)
     nvox = dims[0] * dims[1] * dims[2]
     need = {"linear": nvox, "brick": brick_elems(dims), "vg": 4 * vec4_elems(dims), "quad": 4 * vec4_elems(dims),
-            "vga": 4 * vga_elems(dims)}
+            "vga": 4 * vga_elems(dims), "labcell": 2 * vec4_elems(dims)}
+    if lab_lay == "labcell" and lay != "quad":
+        raise ValueError("label cells (upload_label_cells) go with 'quad' intensity grids")
     vols = []
     for m in range(4):
         v = intensities[m] if m < len(intensities) else None
@@ -217,7 +245,13 @@ def _bind_brats(params, intensities, labels, preds, ext, dev, pred_stream: bool 
     prd = _as_device_tensor(preds, torch.int32, dev, "gPreds")
     if P.showSeg != 0 and (lab is None or lab.numel() < need[lab_lay]):
         raise ValueError("showSeg is set but gLabels is missing or too small")
-    if P.showPred != 0 and not pred_stream and (prd is None or prd.numel() < need[lab_lay]):
+    if lab_lay == "labcell":
+        if pred_stream:
+            raise ValueError("label cells carry the prediction grid: not with a class stream")
+        if P.showPred != 0 and (lab is None or lab.numel() < need[lab_lay]):
+            raise ValueError("showPred is set but the label-cell grid is missing or too small")
+        prd = None
+    elif P.showPred != 0 and not pred_stream and (prd is None or prd.numel() < need[lab_lay]):
         raise ValueError("showPred is set but gPreds is missing or too small")
     return P, E, vols, lab, prd
 
@@ -247,12 +281,14 @@ def _bind_skip(P, E, intensities, labels, preds, dev, stream):
                 raise ValueError(f"skip=True: gIntensity{m} must be a Grid made by upload_grid (it carries the macro-cell bounds)")
             S.macroUb[m] = g.macro.data_ptr()
             keep.append(g.macro)
-    for name, g, flag in (("macroSeg", labels, P.showSeg), ("macroPred", preds, P.showPred)):
+    cells = isinstance(labels, Grid) and labels.layout == "labcell"      # one grid carries both summaries
+    for name, g, flag, which in (("macroSeg", labels, P.showSeg, "macro"), ("macroPred", labels if cells else preds, P.showPred, "macro2" if cells else "macro")):
         if flag != 0:
-            if not isinstance(g, Grid) or g.macro is None or g.macro.dtype != torch.int32:
-                raise ValueError("skip=True: a shown label grid must be a Grid made by upload_grid")
-            setattr(S, name, g.macro.data_ptr())
-            keep.append(g.macro)
+            m = getattr(g, which, None) if isinstance(g, Grid) else None
+            if m is None or m.dtype != torch.int32:
+                raise ValueError("skip=True: a shown label grid must be a Grid made by upload_grid / upload_label_cells")
+            setattr(S, name, m.data_ptr())
+            keep.append(m)
     d = (C.c_uint32 * 3)(*[int(v) for v in P.dims])
     words = int(_lib.lib().mrirt_skip_mask_words(d))
     sid = stream if stream is not None else torch.cuda.current_stream()

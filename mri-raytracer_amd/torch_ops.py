@@ -120,6 +120,8 @@ def _grid_need(dims: Sequence[int], layout: int) -> int:
         return int(l.mrirt_brick_elems(d))
     if layout == _lib.LAYOUT_VGA:                    # three axis-flat copies of the float4 voxels
         return 4 * int(l.mrirt_vga_elems(d))
+    if layout == _lib.LAYOUT_LABCELL:                # both overlays' corner labels per cell: 8 bytes per element
+        return 2 * int(l.mrirt_vec4_elems(d))
     return 4 * int(l.mrirt_vec4_elems(d))
 
 
@@ -140,8 +142,9 @@ def render_brats(params: torch.Tensor, ext: torch.Tensor, vol0: Optional[torch.T
             raise ValueError(f"gIntensity{m} is enabled but holds {0 if v is None else v.numel()} < {need} elements")
     if P.showSeg != 0 and (lab is None or lab.numel() < lneed):
         raise ValueError("showSeg is set but gLabels is missing or too small")
-    if P.showPred != 0 and (prd is None or prd.numel() < lneed):
-        raise ValueError("showPred is set but gPreds is missing or too small")
+    cells = E.labelLayout == _lib.LAYOUT_LABCELL     # gLabels carries both grids, gPreds is ignored
+    if P.showPred != 0 and ((lab if cells else prd) is None or (lab if cells else prd).numel() < lneed):
+        raise ValueError("showPred is set but gPreds (or the label-cell grid) is missing or too small")
     dev = _one_device([(f"gIntensity{m}", v) for m, v in enumerate(vols)] + [("gLabels", lab), ("gPreds", prd)])
     dt = torch.float16 if E.outFormat == _lib.OUT_RGBA16F else torch.float32
     vp = (C.c_void_p * 4)(*[C.c_void_p(v.data_ptr()) if v is not None else None for v in vols])

@@ -467,10 +467,11 @@ def test_c2_full_size_against_the_oracle(env):
     lab = synth.synth_labels(n)
     p = synth.brats_scene(n, image, steps, channels=4, show_seg=True, intensity_alpha=0.4)
     ref, aux = oc.brats_main(p, vols, lab, None, None, return_aux=True)
-    for layout, lab_layout in (("quad", "brick"), ("linear", "linear")):
+    for layout, lab_layout in (("quad", "brick"), ("quad", "labcell"), ("linear", "linear")):
         g = [mrirt.upload_grid(v, (n, n, n), layout) for v in vols]
-        gl = mrirt.upload_grid(lab, (n, n, n), lab_layout)
-        got, st = mrirt.render_brats(p, g, gl, ext=dict(layout=layout, labelLayout=lab_layout), stats=True, skip=layout == "quad")
+        # ("labcell": the seg overlay as label cells — what bench.py's k1_reference_path and the shim bind on QUAD grids)
+        gl = mrirt.upload_label_cells(lab, None, (n, n, n)) if lab_layout == "labcell" else mrirt.upload_grid(lab, (n, n, n), lab_layout)
+        got, st = mrirt.render_brats(p, g, gl, ext=dict(layout=layout, labelLayout=lab_layout), stats=True, skip=layout == "quad" and lab_layout == "brick")
         assert np.array_equal(got.cpu().numpy(), ref), layout
         assert st["live_samples"] == aux["live_samples"]
         del g, gl

@@ -10,7 +10,7 @@ frames = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 variant = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 vols = [synth.synth_volume(n, 1234 + m, phase=0.3 * m) for m in range(4)]
 gv = [mrirt.upload_grid(v, (n, n, n), "quad") for v in vols]
-gl = mrirt.upload_grid(synth.synth_labels(n), (n, n, n), "brick")
+gl = mrirt.upload_label_cells(synth.synth_labels(n), None, (n, n, n))      # as bench.py's k1_reference_path and the shim bind it
 p = synth.brats_scene(n, image, steps, channels=4, show_seg=True, intensity_alpha=0.4)
 out = torch.empty((image, image, 4), device="cuda")
 for _ in range(3):
