@@ -34,9 +34,10 @@ vols = [synth.synth_volume(n, 1234 + m, phase=0.3 * m) for m in range(4)]
 lab = synth.synth_labels(n)
 p2 = synth.brats_scene(n, 512, 256, channels=4, show_seg=True, intensity_alpha=0.4)
 t = time.perf_counter(); ref2, aux2 = oracle_c.brats_main(p2, vols, lab, None, return_aux=True); dt2 = time.perf_counter() - t
-for layout in ("linear", "brick", "quad"):
-    gv = [mrirt.upload_grid(v, (n, n, n), layout) for v in vols]
-    gl = mrirt.upload_grid(lab, (n, n, n), "linear" if layout == "linear" else "brick")
+for layout in ("linear", "brick", "quad", "quad+cells"):
+    cells = layout == "quad+cells"                  # the seg overlay as label cells (what the shim binds on QUAD frames)
+    gv = [mrirt.upload_grid(v, (n, n, n), "quad" if cells else layout) for v in vols]
+    gl = mrirt.upload_label_cells(lab, None, (n, n, n)) if cells else mrirt.upload_grid(lab, (n, n, n), "linear" if layout == "linear" else "brick")
     for math_ in ("strict", "fast"):
         e = dict(math=math_)
         img = mrirt.render_brats(p2, gv, gl, ext=e)
