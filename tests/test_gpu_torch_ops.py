@@ -26,6 +26,19 @@ def test_render_brats_op_equals_api_and_oracle():
                                           g.data, None, None, None, labels, None)
         assert torch.equal(op, api)
         assert np.array_equal(op.cpu().numpy(), ref)
+    # QUAD voxels + label cells (both overlays in one grid, bound as gLabels; gPreds unused), both operator libraries
+    q = dict(p, showPred=1)
+    pred = np.roll(lab, 7)
+    refq = oracle_c.brats_main(q, [vol], lab, pred, None)
+    gq = mrirt.upload_grid(vol, (n, n, n), "quad")
+    cells = mrirt.upload_label_cells(lab, pred, (n, n, n))
+    extq = dict(layout="quad", labelLayout="labcell")
+    opq = torch.ops.mrirt.render_brats(torch_ops.pack_brats_params(q), torch_ops.pack_render_ext(extq), gq.data, None, None, None, cells.data, None)
+    assert np.array_equal(opq.cpu().numpy(), refq)
+    assert torch.equal(torch_ops.load_native().render_brats(torch_ops.pack_brats_params(q), torch_ops.pack_render_ext(extq),
+                                                            gq.data, None, None, None, cells.data, None), opq)      # the C++ extension
+    with pytest.raises(ValueError):
+        torch.ops.mrirt.render_brats(torch_ops.pack_brats_params(q), torch_ops.pack_render_ext(extq), gq.data, None, None, None, cells.data[:64], None)
     # the size checks the C ABI cannot make
     with pytest.raises(ValueError):
         torch.ops.mrirt.render_brats(torch_ops.pack_brats_params(p), torch_ops.pack_render_ext(ext),
