@@ -129,3 +129,28 @@ def test_label_cells_refuse_what_they_cannot_serve(env):
         mrirt.render_brats(p, [mrirt.upload_grid(vol, dims, "vg")], labels=cells, ext=dict(layout="vg"))
     with pytest.raises(ValueError):
         mrirt.upload_label_cells(lab[:-1], None, dims)
+
+
+def test_label_cells_with_real_empty_space_skipping(env):
+    """A head in air (most macro cells skippable, one label blob floating in the air): the skipping kernels read the cells
+    through fetch_labels — same bits and counters as the plain launch and as the two-grid path."""
+    mrirt, synth, oc = env
+    import torch
+    from test_gpu_skip import head_in_air, mask_fraction
+    n, image = 72, 160
+    vols, lab = head_in_air(n, channels=2)
+    pred = np.roll(lab, 11).copy()
+    p = synth.brats_scene(n, image, 192, channels=2, show_seg=True, show_pred=True, intensity_alpha=6.0)
+    p["wl"], p["ww"] = np.float32(0.45), np.float32(0.7)
+    grids = [mrirt.upload_grid(v, (n, n, n), "quad") for v in vols]
+    cells = mrirt.upload_label_cells(lab, pred, (n, n, n))
+    gl, gp = mrirt.upload_grid(lab, (n, n, n), "linear"), mrirt.upload_grid(pred, (n, n, n), "linear")
+    two, s2 = mrirt.render_brats(p, grids, labels=gl, preds=gp, ext=dict(layout="quad"), stats=True)
+    for math in ("strict", "fast"):
+        ext = dict(layout="quad", math=math)
+        plain, s0 = mrirt.render_brats(p, grids, labels=cells, ext=ext, stats=True)
+        skipped, s1 = mrirt.render_brats(p, grids, labels=cells, ext=ext, stats=True, skip=True)
+        assert torch.equal(plain, skipped) and s0 == s1
+        assert mask_fraction((n, n, n)) > 0.5
+        if math == "strict":
+            assert torch.equal(plain, two) and s0 == s2
