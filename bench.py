@@ -240,26 +240,22 @@ def inr_path(dev, frames=5):
     cls = torch.empty(nq, dtype=torch.int16, device=dev)
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
-    def launch():
-        _lib.check(_lib.lib().mrirt_inr_forward(C.byref(net.desc), C.c_void_p(coords.data_ptr()), C.c_void_p(feats.data_ptr()),
+    def launch(desc):
+        _lib.check(_lib.lib().mrirt_inr_forward(C.byref(desc), C.c_void_p(coords.data_ptr()), C.c_void_p(feats.data_ptr()),
                                                 nq, None, C.c_void_p(cls.data_ptr()), stream), "mrirt_inr_forward")
-    def timed():
+    def timed(desc):
         for _ in range(3):
-            launch()
+            launch(desc)
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
         for e0, e1 in ev:
-            e0.record(); launch(); e1.record()
+            e0.record(); launch(desc); e1.record()
         torch.cuda.synchronize()
         return float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))
 
-    # the bf16 MFMA pass by itself (the library reads the switch at every launch), then the class output as shipped:
-    # bf16 pass + split-bf16 re-evaluation of the near-tie points
-    os.environ["MRIRT_INR_NO_REFINE"] = "1"
-    try:
-        ms = timed()
-    finally:
-        del os.environ["MRIRT_INR_NO_REFINE"]
-    ms_refined = timed()
+    # the bf16 MFMA pass with its near-tie MARKING but no second pass (MrirtInrDesc.flags = MRIRT_INR_MARK_ONLY), then the
+    # class output as shipped: bf16 pass + split-bf16 re-evaluation of the marked points
+    ms = timed(inr.with_flags(net, mark_only=True).desc)
+    ms_refined = timed(net.desc)
     marked = float(inr.calibration(net)["rms_error"])
     tflops = flop * nq / (ms * 1e-3) / 1e12
     return {"workload": "C5 frame: 256^3 x 4 modalities + seg, 512x512 px, 256 samples/ray, per-sample SIREN 7->4x256->4 "

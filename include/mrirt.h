@@ -24,7 +24,9 @@
 extern "C" {
 #endif
 
-#define MRIRT_ABI_VERSION 2
+/* 3: MRIRT_LAYOUT_LABCELL + mrirt_build_label_cells, MrirtInrDesc.flags / tieSigmas (they replace the process-environment
+ *    switches of version 2), mrirt_brats_skip_applicable, mrirt_install_abort_trace. */
+#define MRIRT_ABI_VERSION 3
 
 typedef enum MrirtStatus {
     MRIRT_OK = 0,
@@ -267,6 +269,13 @@ int mrirt_render_brats_skip(const MrirtBratsParams* params, const MrirtRenderExt
                             const void* const vol[4], const void* labels, const void* preds,
                             const MrirtSkip* skip, void* out_rgba, int64_t pitch_px,
                             uint64_t* stats_dev, void* stream);
+/* Host-only query, nothing is launched: 1 = mrirt_render_brats_skip with these arguments marches with an empty-radius map
+ * (it builds one into skip->mask, or trusts skip->mapReady); 0 = it is the plain launch and never reads or writes
+ * skip->mask (window width or gamma <= 0, a negative weight, a layout / modality count / math mode without a skipping
+ * kernel, more than 256 macro cells on an axis, a missing summary): a caller that caches maps must not mark such a scratch
+ * as holding one.  < 0: the MrirtStatus the render call would return for these arguments.                               */
+int mrirt_brats_skip_applicable(const MrirtBratsParams* params, const MrirtRenderExt* ext, const void* const vol[4],
+                                const void* labels, const void* preds, const MrirtSkip* skip);
 
 /* ------------------------------------------------------------------------------------ */
 /* number of tiles rank `rank` of `world` renders for a W x H image */
@@ -296,7 +305,17 @@ typedef struct MrirtInrDesc {
     float    w0;             /* SIREN first-layer frequency (30)                                */
     const void* weights;     /* device: packed bf16 weights, see mrirt_inr_pack_bytes           */
     const float* biases;     /* device: fp32 biases, layers concatenated, each padded to its padded out width */
+    uint32_t flags;          /* MrirtInrFlags; 0 = the library's defaults                       */
+    float    tieSigmas;      /* near-tie mark: top-2 gap < tieSigmas * sqrt(2) * calibrated rms error; 0 = default (3) */
 } MrirtInrDesc;
+
+/* A/B switches of the INR forward (measurement and tests; every combination computes the same classes up to the near-tie
+ * refinement they switch off).  Version 2 read these from the process environment at every launch.                      */
+typedef enum MrirtInrFlags {
+    MRIRT_INR_NO_WEIGHT_STATIONARY = 1,  /* 4 x 256 SIRENs take the streaming kernel instead of the weight-stationary one */
+    MRIRT_INR_NO_REFINE = 2,             /* no near-tie marking and no second pass: classes are the bf16 pass's           */
+    MRIRT_INR_MARK_ONLY = 4              /* mark near-ties (bit 14 of the stored class) but run no second pass            */
+} MrirtInrFlags;
 
 /* bytes to allocate for the packed weight buffer of a network shape (0: unsupported shape): the bf16 MFMA image,
  * 64 KiB of slack (the kernel's last weight-chunk prefetch reads and ignores it), the split-bf16 (hi + lo) image the
@@ -353,7 +372,13 @@ int mrirt_render_brats_inr(const MrirtBratsParams* params, const MrirtRenderExt*
 int mrirt_abi_version(void);
 const char* mrirt_status_string(int status);
 int mrirt_last_hip_error(void);            /* hipError_t of the last failed HIP call on this thread */
-uint32_t mrirt_sizeof(uint32_t which);     /* 0 BratsParams, 1 RenderExt, 2 VolumeParams, 3 SdfParams, 4 InrDesc */
+uint32_t mrirt_sizeof(uint32_t which);     /* 0 BratsParams, 1 RenderExt, 2 VolumeParams, 3 SdfParams, 4 InrDesc, 5 Skip */
+/* Opt-in diagnostics (host only; the library installs nothing by itself): a SIGABRT handler that writes the native
+ * backtrace of the aborting thread and, when file descriptor 2 has been redirected into a regular file (a test runner's
+ * capture), the tail of that file to `fd` — a descriptor the caller duplicated before the redirection — and then chains
+ * to the handler that was installed before it.  The ROCm runtime reports GPU faults as a line on stderr + abort() from
+ * its event thread; under a capturing runner that line is otherwise lost with the process.                              */
+int mrirt_install_abort_trace(int fd);
 
 #ifdef __cplusplus
 }

@@ -9,13 +9,15 @@ import ctypes as C
 import os
 import pathlib
 import subprocess
+import sys
 from typing import List, Optional
 
 PKG_DIR = pathlib.Path(__file__).resolve().parent
 CSRC = PKG_DIR / "csrc"
 INCLUDE = PKG_DIR.parent / "include"
 SO_PATH = pathlib.Path(os.environ.get("MRIRT_LIB", PKG_DIR / "libmrirt.so"))   # override: A/B builds in development
-HIP_SOURCES = ["brats_march.hip", "brats_slab.hip", "brats_ring.hip", "volume_march.hip", "grid_ops.hip", "inr_mlp.hip"]
+HIP_SOURCES = ["brats_march.hip", "brats_slab.hip", "brats_ring.hip", "volume_march.hip", "grid_ops.hip", "inr_mlp.hip",
+               "abort_trace.cpp"]
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17", "-Wall"]
 
 # every extern "C" symbol include/mrirt.h declares
@@ -26,16 +28,17 @@ ABI_SYMBOLS = [
     "mrirt_build_macro_max", "mrirt_build_macro_labels", "mrirt_render_brats_skip", "mrirt_render_volume", "mrirt_build_cell8", "mrirt_render_sdf", "mrirt_tiles_for_rank",
     "mrirt_detile", "mrirt_inr_pack_bytes", "mrirt_inr_pack_weights", "mrirt_inr_calibrate", "mrirt_inr_forward", "mrirt_inr_forward_refined",
     "mrirt_inr_predict_volume", "mrirt_abi_version", "mrirt_status_string", "mrirt_last_hip_error",
-    "mrirt_sizeof",
+    "mrirt_sizeof", "mrirt_brats_skip_applicable", "mrirt_install_abort_trace",
 ]
 
-ABI_VERSION = 2          # MRIRT_ABI_VERSION of include/mrirt.h this binding was written against
+ABI_VERSION = 3          # MRIRT_ABI_VERSION of include/mrirt.h this binding was written against
 OK = 0
 LAYOUT_LINEAR, LAYOUT_BRICK, LAYOUT_VG, LAYOUT_QUAD, LAYOUT_VGA, LAYOUT_LABCELL = 0, 1, 2, 3, 4, 5
 MATH_STRICT, MATH_FAST = 0, 1
 OUT_RGBA32F, OUT_RGBA16F = 0, 1
 VOX_U32X4, VOX_U8, VOX_F32, VOX_CELL8 = 0, 1, 2, 3
 INR_FOURIER_RELU, INR_SIREN = 0, 1
+INR_NO_WEIGHT_STATIONARY, INR_NO_REFINE, INR_MARK_ONLY = 1, 2, 4      # MrirtInrFlags
 
 f32, u32 = C.c_float, C.c_uint32
 
@@ -92,6 +95,7 @@ class InrDesc(C.Structure):
         ("kind", u32), ("numLayers", u32), ("inDim", u32), ("outDim", u32), ("hidden", u32),
         ("fourierFreqs", u32), ("numMods", u32), ("w0", f32),
         ("weights", C.c_void_p), ("biases", C.c_void_p),
+        ("flags", u32), ("tieSigmas", f32),
     ]
 
 
@@ -110,30 +114,74 @@ class MrirtError(RuntimeError):
         self.status = status
 
 
+OBJ_DIR = PKG_DIR / "build"          # per-source objects (git-ignored; they do not travel to history)
+
+
+def _hipcc() -> str:
+    return os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
 def hipcc_command(out: Optional[pathlib.Path] = None, extra: Optional[List[str]] = None) -> List[str]:
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    return [hipcc, *HIPCC_FLAGS, *(extra or []), f"-I{INCLUDE}", *[str(CSRC / s) for s in HIP_SOURCES],
+    """The one-command form of the build (every source in one hipcc call); build() compiles the same sources with the same
+    flags one object at a time, in parallel, and links them."""
+    return [_hipcc(), *HIPCC_FLAGS, *(extra or []), f"-I{INCLUDE}", *[str(CSRC / s) for s in HIP_SOURCES],
             "-o", str(out or SO_PATH)]
+
+
+def _headers() -> List[pathlib.Path]:
+    return list(CSRC.glob("*.h")) + [INCLUDE / "mrirt.h"]
 
 
 def _stale() -> bool:
     if not SO_PATH.exists():
         return True
     t = SO_PATH.stat().st_mtime
-    srcs = list(CSRC.glob("*.hip")) + list(CSRC.glob("*.h")) + [INCLUDE / "mrirt.h"]
+    srcs = [CSRC / s for s in HIP_SOURCES] + _headers()
     return any(p.stat().st_mtime > t for p in srcs)
 
 
-def build(force: bool = False, verbose: bool = False) -> pathlib.Path:
-    """Cross-compile every HIP source for gfx950 into the in-tree libmrirt.so (no GPU needed)."""
-    if force or _stale():
-        cmd = hipcc_command()
-        r = subprocess.run(cmd, capture_output=True, text=True)
+def build(force: bool = False, verbose: bool = False, check: bool = True) -> pathlib.Path:
+    """Cross-compile every HIP source for gfx950 into the in-tree libmrirt.so (no GPU needed): one object per source, the
+    stale ones in parallel, then one link.  A rebuilt library is then checked by tools/check_async_loads.py — the
+    pipelined march kernels issue their gathers as inline asm and retire them with hand-counted waits, which is sound only
+    as long as no instruction touches a gather destination before its wait; that scan is a correctness gate of the build,
+    whichever path (``__graft_entry__.build()``, the test session's rebuild of a stale library) triggered it."""
+    if not (force or _stale()):
+        return SO_PATH
+    from concurrent.futures import ThreadPoolExecutor
+    OBJ_DIR.mkdir(exist_ok=True)
+    hdr_t = max(p.stat().st_mtime for p in _headers())
+    flags = [f for f in HIPCC_FLAGS if f != "-shared"]
+    jobs = []
+    for src in HIP_SOURCES:
+        sp, op = CSRC / src, OBJ_DIR / (src + ".o")
+        if force or not op.exists() or op.stat().st_mtime < max(sp.stat().st_mtime, hdr_t):
+            jobs.append([_hipcc(), *flags, f"-I{INCLUDE}", "-c", str(sp), "-o", str(op)])
+
+    def run(cmd):
+        return cmd, subprocess.run(cmd, capture_output=True, text=True)
+    with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1) or 1) as pool:
+        for cmd, r in pool.map(run, jobs):
+            if verbose or r.returncode != 0:
+                print(" ".join(cmd))
+                print(r.stdout + r.stderr)
+            if r.returncode != 0:
+                raise RuntimeError(f"hipcc failed on {cmd[-3]}")
+    link = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *[str(OBJ_DIR / (s + ".o")) for s in HIP_SOURCES], "-o", str(SO_PATH)]
+    r = subprocess.run(link, capture_output=True, text=True)
+    if verbose or r.returncode != 0:
+        print(" ".join(link))
+        print(r.stdout + r.stderr)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed linking libmrirt.so")
+    if check:
+        tool = PKG_DIR.parent / "tools" / "check_async_loads.py"
+        r = subprocess.run([sys.executable, str(tool), str(SO_PATH)], capture_output=True, text=True)
         if verbose or r.returncode != 0:
-            print(" ".join(cmd))
             print(r.stdout + r.stderr)
         if r.returncode != 0:
-            raise RuntimeError("hipcc failed building libmrirt.so")
+            SO_PATH.unlink(missing_ok=True)         # a library that fails the gate must not be loadable
+            raise RuntimeError("tools/check_async_loads.py rejected the built libmrirt.so (see output above)")
     return SO_PATH
 
 
@@ -220,6 +268,10 @@ def lib() -> C.CDLL:
     l.mrirt_build_macro_labels.restype = i32
     l.mrirt_render_brats_skip.argtypes = [C.POINTER(BratsParams), C.POINTER(RenderExt), C.POINTER(vp), vp, vp, C.POINTER(Skip), vp, i64, vp, vp]
     l.mrirt_render_brats_skip.restype = i32
+    l.mrirt_brats_skip_applicable.argtypes = [C.POINTER(BratsParams), C.POINTER(RenderExt), C.POINTER(vp), vp, vp, C.POINTER(Skip)]
+    l.mrirt_brats_skip_applicable.restype = i32
+    l.mrirt_install_abort_trace.argtypes = [i32]
+    l.mrirt_install_abort_trace.restype = i32
     l.mrirt_build_cell8.argtypes = [vp, u32, C.POINTER(u32), vp, vp]
     l.mrirt_build_cell8.restype = i32
     l.mrirt_bc4_decode.argtypes = [vp, u32, u32, u32, vp, vp]
@@ -248,7 +300,7 @@ def lib() -> C.CDLL:
     if l.mrirt_abi_version() != ABI_VERSION:
         raise ImportError(f"ABI mismatch: {SO_PATH} reports version {l.mrirt_abi_version()}, this binding expects {ABI_VERSION} "
                           "(rebuild: python -c \"import __graft_entry__ as g; g.build()\")")
-    for which, st in enumerate((BratsParams, RenderExt, VolumeParams, SdfParams, InrDesc)):
+    for which, st in enumerate((BratsParams, RenderExt, VolumeParams, SdfParams, InrDesc, Skip)):
         if l.mrirt_sizeof(which) != C.sizeof(st):
             raise ImportError(f"ABI mismatch: {st.__name__} is {C.sizeof(st)} B here, {l.mrirt_sizeof(which)} B in {SO_PATH}")
     _LIB = l

@@ -113,6 +113,22 @@ __device__ __forceinline__ uint32_t wave_max8(uint32_t v) { return 255u - wave_m
 // every ten steps or so; it is placed with the packet's extreme cell at the trailing edge of each axis.  ds_bpermute
 // returns 0 from lanes that are switched off, which is why the skipping march keeps every lane of the wave in its
 // loops (finished rays ride along as `!alive`) instead of letting them exit.
+// MapWindow's index arithmetic (host + device: tests/native/index_harness.hip walks it under ASan / UBSan)
+MRIRT_HD uint32_t window_origin(bool towardsPlus, uint32_t lo, uint32_t hi) { return towardsPlus ? lo : (hi > 3u ? hi : 3u) - 3u; }
+MRIRT_HD bool window_holds(uint32_t cx, uint32_t cy, uint32_t cz, uint32_t ox, uint32_t oy, uint32_t oz) {
+    return (cx - ox) < 4u && (cy - oy) < 4u && (cz - oz) < 4u;
+}
+MRIRT_HD uint32_t window_slot(uint32_t cx, uint32_t cy, uint32_t cz, uint32_t ox, uint32_t oy, uint32_t oz) {
+    return ((cx - ox) + 4u * (cy - oy) + 16u * (cz - oz)) & 63u;
+}
+// the macro cell lane `lane` fetches when the window moves to (ox, oy, oz): clamped into the map
+MRIRT_HD uint32_t window_fetch_index(uint32_t ox, uint32_t oy, uint32_t oz, uint32_t lane, uint32_t mX, uint32_t mY, uint32_t mZ, uint32_t mXY) {
+    const uint32_t gx = ox + (lane & 3u) < mX ? ox + (lane & 3u) : mX - 1u;
+    const uint32_t gy = oy + ((lane >> 2) & 3u) < mY ? oy + ((lane >> 2) & 3u) : mY - 1u;
+    const uint32_t gz = oz + (lane >> 4) < mZ ? oz + (lane >> 4) : mZ - 1u;
+    return gx + gy * mX + gz * mXY;
+}
+
 struct MapWindow {
     uint32_t bytes;                  // lane l: the map byte of macro cell origin + (l & 3, (l >> 2) & 3, l >> 4)
     uint32_t ox, oy, oz;             // wave-uniform
@@ -120,24 +136,21 @@ struct MapWindow {
     // the map byte of the sample's macro cell; `alive` = this lane's sample matters
     __device__ __forceinline__ uint32_t lookup(const K1Args& a, const Cell& s, const float rd[3], bool alive) {
         const uint32_t cx = s.ix >> 3, cy = s.iy >> 3, cz = s.iz >> 3;
-        bool in = (cx - ox) < 4u && (cy - oy) < 4u && (cz - oz) < 4u;
+        bool in = window_holds(cx, cy, cz, ox, oy, oz);
         if (__ballot(alive && !in) != 0) {                           // wave-uniform
             const uint32_t lane = threadIdx.x & 63u;
             // trailing edge per axis, by the first live lane's direction of travel (the packet's rays are near-parallel)
             const int first = __ffsll((long long)__ballot(alive)) - 1;
             const bool px = __shfl(rd[0], first) >= 0.0f, py = __shfl(rd[1], first) >= 0.0f, pz = __shfl(rd[2], first) >= 0.0f;
-            ox = px ? wave_min8(alive ? cx : 255u) : max(wave_max8(alive ? cx : 0u), 3u) - 3u;
-            oy = py ? wave_min8(alive ? cy : 255u) : max(wave_max8(alive ? cy : 0u), 3u) - 3u;
-            oz = pz ? wave_min8(alive ? cz : 255u) : max(wave_max8(alive ? cz : 0u), 3u) - 3u;
-            const uint32_t gx = min(ox + (lane & 3u), a.mX - 1u), gy = min(oy + ((lane >> 2) & 3u), a.mY - 1u),
-                           gz = min(oz + (lane >> 4), a.mZ - 1u);
-            uint32_t v = a.skipDist[gx + gy * a.mX + gz * a.mXY];
+            ox = window_origin(px, wave_min8(alive ? cx : 255u), wave_max8(alive ? cx : 0u));
+            oy = window_origin(py, wave_min8(alive ? cy : 255u), wave_max8(alive ? cy : 0u));
+            oz = window_origin(pz, wave_min8(alive ? cz : 255u), wave_max8(alive ? cz : 0u));
+            uint32_t v = a.skipDist[window_fetch_index(ox, oy, oz, lane, a.mX, a.mY, a.mZ, a.mXY)];
             asm volatile("" : "+v"(v));                             // the wait for this load belongs inside the branch
             bytes = v;
-            in = (cx - ox) < 4u && (cy - oy) < 4u && (cz - oz) < 4u;
+            in = window_holds(cx, cy, cz, ox, oy, oz);
         }
-        const uint32_t li = (cx - ox) + 4u * (cy - oy) + 16u * (cz - oz);
-        const uint32_t d = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((li & 63u) << 2), (int)bytes);
+        const uint32_t d = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(window_slot(cx, cy, cz, ox, oy, oz) << 2), (int)bytes);
         // a ray that strays from the packet (more than 4 macro cells wide: a tiny image over a large volume) is simply
         // not skipped: 0 = fetch and composite, always correct
         return in ? d : 0u;
@@ -1093,6 +1106,10 @@ struct SkipArgs {
     uint32_t* mask;
 };
 
+// (scratch layout: skip_bit_words / skip_map_stride, mrirt_device.h)
+// where lane 0 of the wave whose first cell is `cell` stores its ballot (two words), or -1: no store
+MRIRT_HD int64_t skip_ballot_word(uint32_t cell, uint32_t cells) { return cell < ((cells + 63u) & ~63u) ? (int64_t)(cell >> 5) : -1; }
+
 template <bool STRICT>
 __global__ __launch_bounds__(256) void skip_mask_kernel(const SkipArgs k) {
     using Mm = M<STRICT>;
@@ -1107,34 +1124,41 @@ __global__ __launch_bounds__(256) void skip_mask_kernel(const SkipArgs k) {
         if (k.pred != nullptr && k.pred[cell] != 0u) empty = false;
     }
     const uint64_t bits = __ballot(empty);
-    if ((threadIdx.x & 63u) == 0u && cell < ((k.cells + 63u) & ~63u)) {      // mask holds whole ballots only
-        k.mask[cell >> 5] = (uint32_t)bits;
-        k.mask[(cell >> 5) + 1] = (uint32_t)(bits >> 32);
+    const int64_t w = skip_ballot_word(cell, k.cells);               // mask holds whole ballots only
+    if ((threadIdx.x & 63u) == 0u && w >= 0) {
+        k.mask[w] = (uint32_t)bits;
+        k.mask[w + 1] = (uint32_t)(bits >> 32);
     }
 }
 
 // The distance map from the mask, one axis at a time (box emptiness is separable).  r(c) = largest r <= cap such that
 // every in-grid cell within r - 1 of c along the axes done so far has the property; cells outside the grid never hold a
 // sample, so they do not constrain.  Pass x reads the bits, passes y and z read the previous pass's bytes.
+// `at(cell)` = the previous pass's value of a cell (pass x: cap or 0 from the bit).
+template <int AXIS, class At>
+MRIRT_HD uint32_t skip_dist_cell(uint32_t c, uint32_t mx, uint32_t my, uint32_t mz, At at) {
+    const uint32_t xyz[3] = { c % mx, (c / mx) % my, c / (mx * my) }, ext[3] = { mx, my, mz };
+    const uint32_t stride = AXIS == 0 ? 1u : AXIS == 1 ? mx : mx * my;
+    // m = smallest value within distance r of c; radius r + 1 is good when m >= r + 1
+    uint32_t m = at(c), r = 0;
+    while (r < m && r < kSkipDistCap) {
+        ++r;
+        if (xyz[AXIS] >= r) { const uint32_t v = at(c - r * stride); m = v < m ? v : m; }
+        if (xyz[AXIS] + r < ext[AXIS]) { const uint32_t v = at(c + r * stride); m = v < m ? v : m; }
+    }
+    return r;
+}
+MRIRT_HD uint32_t skip_bit_value(const uint32_t* mask, uint32_t cell) { return ((mask[cell >> 5] >> (cell & 31u)) & 1u) != 0 ? kSkipDistCap : 0u; }
+
 template <int AXIS>
 __global__ __launch_bounds__(256) void skip_dist_kernel(const uint32_t* __restrict__ mask, const uint8_t* __restrict__ prev,
                                                         uint8_t* __restrict__ next, uint32_t mx, uint32_t my, uint32_t mz) {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= mx * my * mz) return;
-    const uint32_t xyz[3] = { c % mx, (c / mx) % my, c / (mx * my) }, ext[3] = { mx, my, mz };
-    const uint32_t stride = AXIS == 0 ? 1u : AXIS == 1 ? mx : mx * my;
-    auto at = [&](uint32_t cell) -> uint32_t {
-        if constexpr (AXIS == 0) return ((mask[cell >> 5] >> (cell & 31u)) & 1u) != 0 ? kSkipDistCap : 0u;
+    next[c] = (uint8_t)skip_dist_cell<AXIS>(c, mx, my, mz, [&](uint32_t cell) -> uint32_t {
+        if constexpr (AXIS == 0) return skip_bit_value(mask, cell);
         else return prev[cell];
-    };
-    // m = smallest value within distance r of c; radius r + 1 is good when m >= r + 1
-    uint32_t m = at(c), r = 0;
-    while (r < m && r < kSkipDistCap) {
-        ++r;
-        if (xyz[AXIS] >= r) m = min(m, at(c - r * stride));
-        if (xyz[AXIS] + r < ext[AXIS]) m = min(m, at(c + r * stride));
-    }
-    next[c] = (uint8_t)r;
+    });
 }
 
 }  // namespace mrirt
@@ -1167,6 +1191,29 @@ extern "C" int mrirt_render_brats_ex(const MrirtBratsParams* p, const MrirtRende
                                          : launch_layout<false>(a, cfg.layout, cfg.shade, cfg.pipe, s);
 }
 
+// Does this launch march with an empty-radius map?  Skipping is sound only where "upper bound <= window floor" implies
+// "contributes nothing": positive window width and gamma (pow(0, g) = 0), non-negative weights (monotone sum), a bound for
+// every enabled modality and a label summary for every shown overlay — and it pays only where the launch has a SKIP kernel:
+// on VG / VGA grids the pipelined kernel (one modality) or the rolling kernel (2-4 modalities, no overlays), on QUAD grids
+// the pipelined kernel (launch()); STRICT with gamma == 1, or FAST (launch_pipe() / launch_roll()).  Anything else would pay
+// the four pre-pass launches for a kernel that ignores the map.  Otherwise: the ordinary launch, no map built.
+static bool skip_applicable(const MrirtBratsParams* p, const K1Args& a, const Prepared& cfg, const MrirtSkip* skip) {
+    bool ok = skip != nullptr && p->ww > 0.0f && p->gamma > 0.0f && a.nch >= 1;      // (the scratch itself: the caller's check)
+    const bool wide = a.grid.wide != 0;
+    const bool overlays = p->showSeg != 0 || p->showPred != 0;
+    const bool layoutOk = ((cfg.layout == MRIRT_LAYOUT_VG && !wide) || cfg.layout == MRIRT_LAYOUT_VGA) ? (a.nch == 1 || !overlays)   // pipelined / rolling
+                        : (cfg.layout == MRIRT_LAYOUT_QUAD && !wide && !cfg.shade);
+    const bool mathOk = cfg.math == MRIRT_MATH_FAST || p->gamma == 1.0f;
+    ok = ok && cfg.pipe && !cfg.slab && !cfg.ring && layoutOk && mathOk;
+    for (int k = 0; k < 3; ++k) ok = ok && (p->dims[k] + 7) / 8 <= 256;   // macro coordinates travel through 8-bit wave reductions
+    for (uint32_t c = 0; c < a.nch && ok; ++c)
+        ok = skip->macroUb[a.chan[c]] != nullptr && a.weight[a.chan[c]] >= 0.0f;
+    if (p->showSeg != 0 && !skip->macroSeg) ok = false;
+    if (p->showPred != 0 && !skip->macroPred) ok = false;
+    // the label overlays of a launch that takes the generic kernel (label grids >= 2^30 elements: launch()) are not skipped
+    return ok;
+}
+
 extern "C" int mrirt_render_brats_skip(const MrirtBratsParams* p, const MrirtRenderExt* ext,
                                        const void* const vol[4], const void* labels, const void* preds,
                                        const MrirtSkip* skip, void* out_rgba, int64_t pitch_px,
@@ -1180,34 +1227,15 @@ extern "C" int mrirt_render_brats_skip(const MrirtBratsParams* p, const MrirtRen
     if (p->showPred != 0 && !preds && a.labCell == nullptr) return MRIRT_ERR_NULL;
     a.out = out_rgba;
     a.stats = stats_dev;
-    if (a.map.numBlocks == 0) return MRIRT_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    // Skipping is sound only where "upper bound <= window floor" implies "contributes nothing": positive
-    // window width and gamma (pow(0, g) = 0), non-negative weights (monotone sum), a bound for every enabled
-    // modality and a label summary for every shown overlay.  Otherwise: the ordinary launch.
-    bool ok = skip->mask != nullptr && p->ww > 0.0f && p->gamma > 0.0f && a.nch >= 1;
-    // ... and only where the launch below has a SKIP kernel: on VG / VGA grids the pipelined kernel (one modality) or the rolling
-    // kernel (2-4 modalities, no overlays), on QUAD grids the pipelined kernel (launch()); STRICT with gamma == 1, or FAST
-    // (launch_pipe() / launch_roll()).  Anything else would pay the four pre-pass launches for a kernel that ignores the map
-    // (with several shaded modalities + overlays that was the generic kernel, slower than without skip=True).
-    {
-        const bool wide = a.grid.wide != 0;
-        const bool overlays = p->showSeg != 0 || p->showPred != 0;
-        const bool layoutOk = ((cfg.layout == MRIRT_LAYOUT_VG && !wide) || cfg.layout == MRIRT_LAYOUT_VGA) ? (a.nch == 1 || !overlays)   // pipelined / rolling
-                            : (cfg.layout == MRIRT_LAYOUT_QUAD && !wide && !cfg.shade);
-        const bool mathOk = cfg.math == MRIRT_MATH_FAST || p->gamma == 1.0f;
-        ok = ok && cfg.pipe && !cfg.slab && layoutOk && mathOk;
-    }
-    for (int k = 0; k < 3; ++k) ok = ok && (p->dims[k] + 7) / 8 <= 256;   // macro coordinates travel through 8-bit wave reductions
-    for (uint32_t c = 0; c < a.nch && ok; ++c)
-        ok = skip->macroUb[a.chan[c]] != nullptr && a.weight[a.chan[c]] >= 0.0f;
-    if (p->showSeg != 0 && !skip->macroSeg) ok = false;
-    if (p->showPred != 0 && !skip->macroPred) ok = false;
+    const bool ok = skip_applicable(p, a, cfg, skip) && skip->mask != nullptr;
     if (ok && (int64_t)skip->maskWords < mrirt_skip_mask_words(p->dims)) return MRIRT_ERR_ARG;
+    // (a rank that owns no tile still builds the map: "this call returned MRIRT_OK" must mean "skip->mask holds the map",
+    // which is what a caller's mapReady on the next frame rests on)
     if (ok && skip->mapReady != 0) {
         // the scratch already holds this configuration's map (the caller vouches for it: MrirtSkip::mapReady)
         const uint32_t mx = (p->dims[0] + 7) / 8, my = (p->dims[1] + 7) / 8, mz = (p->dims[2] + 7) / 8, cells = mx * my * mz;
-        a.skipDist = reinterpret_cast<uint8_t*>(skip->mask + ((cells + 63u) / 64u) * 2u);
+        a.skipDist = reinterpret_cast<uint8_t*>(skip->mask + skip_bit_words(cells));
         a.mX = mx; a.mXY = mx * my; a.mY = my; a.mZ = mz;
         a.leap = (a.debugFlags & 2u) == 0u ? 1u : 0u;
     } else if (ok) {
@@ -1224,8 +1252,8 @@ extern "C" int mrirt_render_brats_skip(const MrirtBratsParams* p, const MrirtRen
         else                               hipLaunchKernelGGL(skip_mask_kernel<false>, grid, block, 0, s, k);
         MRIRT_HIP(hipGetLastError());
         // bits -> distance bytes; the two byte maps follow the bit words in the same scratch (mrirt_skip_mask_words)
-        uint8_t* mapA = reinterpret_cast<uint8_t*>(skip->mask + ((k.cells + 63u) / 64u) * 2u);
-        uint8_t* mapB = mapA + ((k.cells + 3u) & ~3u);
+        uint8_t* mapA = reinterpret_cast<uint8_t*>(skip->mask + skip_bit_words(k.cells));
+        uint8_t* mapB = mapA + skip_map_stride(k.cells);
         hipLaunchKernelGGL(skip_dist_kernel<0>, grid, block, 0, s, skip->mask, (const uint8_t*)nullptr, mapA, mx, my, mz);
         hipLaunchKernelGGL(skip_dist_kernel<1>, grid, block, 0, s, skip->mask, (const uint8_t*)mapA, mapB, mx, my, mz);
         hipLaunchKernelGGL(skip_dist_kernel<2>, grid, block, 0, s, skip->mask, (const uint8_t*)mapB, mapA, mx, my, mz);
@@ -1233,8 +1261,21 @@ extern "C" int mrirt_render_brats_skip(const MrirtBratsParams* p, const MrirtRen
         a.skipDist = mapA; a.mX = mx; a.mXY = mx * my; a.mY = my; a.mZ = mz;
         a.leap = (a.debugFlags & 2u) == 0u ? 1u : 0u;                 // kernelVariant bit 8: first level only (A/B timing)
     }
+    if (a.map.numBlocks == 0) return MRIRT_OK;
     return cfg.math == MRIRT_MATH_STRICT ? launch_layout<true>(a, cfg.layout, cfg.shade, cfg.pipe, s)
                                          : launch_layout<false>(a, cfg.layout, cfg.shade, cfg.pipe, s);
+}
+
+// 1: mrirt_render_brats_skip with these arguments builds (or reuses) an empty-radius map and marches with it; 0: it is the
+// plain launch and never touches skip->mask (callers then need no scratch); < 0: the status the render call would return.
+extern "C" int mrirt_brats_skip_applicable(const MrirtBratsParams* p, const MrirtRenderExt* ext, const void* const vol[4],
+                                           const void* labels, const void* preds, const MrirtSkip* skip) {
+    if (!skip) return 0;
+    K1Args a;
+    Prepared cfg;
+    const int rc = prepare(p, ext, vol, labels, preds, true, p ? (int64_t)p->imageSize[0] : 0, a, cfg);
+    if (rc != MRIRT_OK) return rc;
+    return skip_applicable(p, a, cfg, skip) ? 1 : 0;
 }
 
 extern "C" int mrirt_render_brats(const MrirtBratsParams* params, const float* const vol[4],

@@ -315,7 +315,8 @@ extern "C" int64_t mrirt_skip_mask_words(const uint32_t dims[3]) {      // whole
     // the 8^3 macro-cell bits, then two byte maps (one byte per macro cell, padded to words): the distance map and the
     // scratch of its separable passes
     const int64_t cells = mrirt_macro_cells(dims);
-    return ((cells + 63) / 64) * 2 + 2 * ((cells + 3) / 4);
+    if (cells >= (1ll << 31)) return 0;
+    return (int64_t)skip_bit_words((uint32_t)cells) + 2 * (int64_t)(skip_map_stride((uint32_t)cells) / 4u);
 }
 
 static int macro_common(const void* lin, void* out, const uint32_t dims[3], bool labels, void* stream) {
@@ -402,6 +403,7 @@ extern "C" uint32_t mrirt_sizeof(uint32_t which) {
         case 2: return (uint32_t)sizeof(MrirtVolumeParams);
         case 3: return (uint32_t)sizeof(MrirtSdfParams);
         case 4: return (uint32_t)sizeof(MrirtInrDesc);
+        case 5: return (uint32_t)sizeof(MrirtSkip);
         default: return 0;
     }
 }

@@ -217,6 +217,8 @@ struct InrArgs {
     const float* tie;          // calibration record of the packed net (tail[0] = rms logit error); nullptr: no marking
     float tieScale;            // mark when (best - second) < tieScale * tie[0]
     uint32_t refineAll;        // inr_refine_kernel: every point, not only the marked ones (calibration, mrirt_inr_forward_refined)
+    uint32_t flags;            // MrirtInrFlags of the descriptor (read by the launchers only)
+    float tieSigmas;           // the descriptor's; 0 = kTieSigmas
 };
 
 // top-2 tracking for the near-tie mark: v joins (best, second); strict > keeps the first maximum (np.argmax)
@@ -1504,7 +1506,7 @@ static int launch_inr_kt0(const InrArgs& a, hipStream_t s) {
 }
 
 static int launch_inr_main(const InrArgs& a, hipStream_t s) {
-    if (ws_eligible(a) && getenv("MRIRT_INR_NO_WS") == nullptr) return launch_inr_ws(a, s);
+    if (ws_eligible(a) && !(a.flags & MRIRT_INR_NO_WEIGHT_STATIONARY) && !debug_env("MRIRT_INR_NO_WS")) return launch_inr_ws(a, s);
     if ((a.n + kInrWaves * 32 - 1) / (kInrWaves * 32) >= (1ll << 31)) return MRIRT_ERR_ARG;
     switch (a.L.hidden) {
         case 32: return launch_inr_kt0<32>(a, s);
@@ -1541,22 +1543,22 @@ static int launch_refine(const InrArgs& a, hipStream_t s) {
     }
 }
 
-// near-tie marking + refinement can be switched off for A/B measurements (the classes are then the bf16 pass's)
-static bool refine_enabled() { return getenv("MRIRT_INR_NO_REFINE") == nullptr; }
-static float tie_sigmas() {
-    const char* e = getenv("MRIRT_INR_TIE_SIGMAS");
-    const float v = e ? (float)atof(e) : 0.0f;
-    return v > 0.0f ? v : kTieSigmas;
-}
-
+// near-tie marking + refinement can be switched off for A/B measurements (MrirtInrDesc.flags; the classes are then the bf16 pass's)
 static int launch_inr(InrArgs a, hipStream_t s) {
     if (a.n <= 0) return MRIRT_OK;
-    const bool refine = a.argmax != nullptr && a.tie != nullptr && refine_enabled() && !a.refineAll;
     if (a.refineAll) return launch_refine(a, s);
-    if (!refine) a.tie = nullptr;
-    else a.tieScale = tie_sigmas() * 1.41421356f;        // the gap of two logits carries two errors
+    const bool off = (a.flags & MRIRT_INR_NO_REFINE) != 0 || debug_env("MRIRT_INR_NO_REFINE");
+    const bool mark = a.argmax != nullptr && a.tie != nullptr && !off;
+    if (!mark) a.tie = nullptr;
+    else {
+        float sig = a.tieSigmas > 0.0f ? a.tieSigmas : kTieSigmas;
+#ifdef MRIRT_DEBUG_ENV
+        if (const char* e = getenv("MRIRT_INR_TIE_SIGMAS")) { const float v = (float)atof(e); if (v > 0.0f) sig = v; }
+#endif
+        a.tieScale = sig * 1.41421356f;                  // the gap of two logits carries two errors
+    }
     int rc = launch_inr_main(a, s);
-    if (rc != MRIRT_OK || !refine) return rc;
+    if (rc != MRIRT_OK || !mark || (a.flags & MRIRT_INR_MARK_ONLY) != 0) return rc;
     return launch_refine(a, s);
 }
 
@@ -1571,6 +1573,7 @@ static int fill_args(const MrirtInrDesc* d, InrArgs& a) {
     a.logits = nullptr; a.argmax = nullptr;
     a.tie = reinterpret_cast<const float*>(a.wpack + (size_t)tail_frag(a.L) * 64);     // written by mrirt_inr_pack_weights
     a.tieScale = 0.0f; a.refineAll = 0;
+    a.flags = d->flags; a.tieSigmas = d->tieSigmas;
     return MRIRT_OK;
 }
 

@@ -13,6 +13,18 @@ constexpr int kTilePx = 8;         // one wave = 8x8 pixels (the reference's num
 constexpr int kBlockPx = 16;       // one 256-thread workgroup = 2x2 waves = 16x16 pixels
 constexpr int kXcds = 8;
 
+// Pure index arithmetic (which element / byte / pixel an id maps to) is compiled for the host as well: the kernels use it as
+// always, and tests/native/index_harness.hip walks the same functions on the CPU under AddressSanitizer + UBSan against
+// buffers of exactly the sizes the host wrappers allocate (GPU sanitizers are not available; VERDICT r3 #1b).
+#define MRIRT_HD __host__ __device__ __forceinline__
+MRIRT_HD uint32_t mul24(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul24(a, b);                       // both factors < 2^24 (callers' contract): v_mul_u32_u24
+#else
+    return a * b;
+#endif
+}
+
 // ---------------------------------------------------------------------------------------
 // math
 // ---------------------------------------------------------------------------------------
@@ -194,7 +206,7 @@ struct GridDims {
 struct CellOffsets {
     uint32_t o, dx, dy, dz;    // float4 units
 };
-__device__ __forceinline__ CellOffsets vec4_cell(const GridDims& g, uint32_t ix, uint32_t iy, uint32_t iz) {
+MRIRT_HD CellOffsets vec4_cell(const GridDims& g, uint32_t ix, uint32_t iy, uint32_t iz) {
     const uint32_t bx = ix & 1u, by = iy & 1u, bz = iz & 1u;
     CellOffsets c;
     c.o = (((ix >> 1) << 3) + bx) + ((iy >> 1) * g.sY + (by << 1)) + ((iz >> 1) * g.sZ + (bz << 2));
@@ -218,13 +230,13 @@ struct FlatAxis {
 };
 struct VgaDims { FlatAxis ax[3]; };
 
-__device__ __forceinline__ CellOffsets flat_cell(const FlatAxis& f, uint32_t ix, uint32_t iy, uint32_t iz) {
+MRIRT_HD CellOffsets flat_cell(const FlatAxis& f, uint32_t ix, uint32_t iy, uint32_t iz) {
     const uint32_t i[3] = { ix, iy, iz };
     uint32_t o = 0, d[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const uint32_t lo = i[k] & f.mask[k];
-        o += __umul24(i[k] >> f.sh[k], f.mul[k]) + __umul24(lo, f.inner[k]);      // < 2^24 each factor (dims <= 2^13)
+        o += mul24(i[k] >> f.sh[k], f.mul[k]) + mul24(lo, f.inner[k]);      // < 2^24 each factor (dims <= 2^13)
         d[k] = lo == f.mask[k] ? f.wrap[k] : f.inner[k];
     }
     CellOffsets c;
@@ -256,21 +268,21 @@ __device__ __forceinline__ f32x2 trilerp2(f32x2 c000, f32x2 c100, f32x2 c010, f3
 
 template <int LAYOUT> struct Addr;
 template <> struct Addr<0> {
-    static __device__ __forceinline__ uint32_t ox(const GridDims&, uint32_t x) { return x; }
-    static __device__ __forceinline__ uint32_t oy(const GridDims& g, uint32_t y) { return y * g.sY; }
-    static __device__ __forceinline__ uint32_t oz(const GridDims& g, uint32_t z) { return z * g.sZ; }
+    static MRIRT_HD uint32_t ox(const GridDims&, uint32_t x) { return x; }
+    static MRIRT_HD uint32_t oy(const GridDims& g, uint32_t y) { return y * g.sY; }
+    static MRIRT_HD uint32_t oz(const GridDims& g, uint32_t z) { return z * g.sZ; }
 };
 template <> struct Addr<1> {
-    static __device__ __forceinline__ uint32_t ox(const GridDims&, uint32_t x) { return ((x >> 2) << 5) + (x & 3u); }
-    static __device__ __forceinline__ uint32_t oy(const GridDims& g, uint32_t y) { return (y >> 2) * g.sY + ((y & 3u) << 2); }
-    static __device__ __forceinline__ uint32_t oz(const GridDims& g, uint32_t z) { return (z >> 1) * g.sZ + ((z & 1u) << 4); }
+    static MRIRT_HD uint32_t ox(const GridDims&, uint32_t x) { return ((x >> 2) << 5) + (x & 3u); }
+    static MRIRT_HD uint32_t oy(const GridDims& g, uint32_t y) { return (y >> 2) * g.sY + ((y & 3u) << 2); }
+    static MRIRT_HD uint32_t oz(const GridDims& g, uint32_t z) { return (z >> 1) * g.sZ + ((z & 1u) << 4); }
 };
 // VG / QUAD: one float4 per voxel, 2x2x2-voxel bricks (8 x 16 B = one 128-B line); offsets in
 // float4 units; sY = NBX*8, sZ = NBX*NBY*8 with NB* = ceil(dim/2).
 struct AddrVec4 {
-    static __device__ __forceinline__ uint32_t ox(const GridDims&, uint32_t x) { return ((x >> 1) << 3) + (x & 1u); }
-    static __device__ __forceinline__ uint32_t oy(const GridDims& g, uint32_t y) { return (y >> 1) * g.sY + ((y & 1u) << 1); }
-    static __device__ __forceinline__ uint32_t oz(const GridDims& g, uint32_t z) { return (z >> 1) * g.sZ + ((z & 1u) << 2); }
+    static MRIRT_HD uint32_t ox(const GridDims&, uint32_t x) { return ((x >> 1) << 3) + (x & 1u); }
+    static MRIRT_HD uint32_t oy(const GridDims& g, uint32_t y) { return (y >> 1) * g.sY + ((y & 1u) << 1); }
+    static MRIRT_HD uint32_t oz(const GridDims& g, uint32_t z) { return (z >> 1) * g.sZ + ((z & 1u) << 2); }
 };
 template <> struct Addr<2> : AddrVec4 {};
 template <> struct Addr<3> : AddrVec4 {};
@@ -279,7 +291,7 @@ template <> struct Addr<3> : AddrVec4 {};
 // shift/mask form that covers LINEAR (shift 0, mask 0) and BRICK.
 struct LabelAddr {
     uint32_t sh[3], mask[3], inner[3], mul[3];
-    __device__ __forceinline__ uint32_t off(uint32_t x, uint32_t y, uint32_t z) const {
+    MRIRT_HD uint32_t off(uint32_t x, uint32_t y, uint32_t z) const {
         return ((x >> sh[0]) * mul[0] + (x & mask[0]) * inner[0]) +
                ((y >> sh[1]) * mul[1] + (y & mask[1]) * inner[1]) +
                ((z >> sh[2]) * mul[2] + (z & mask[2]) * inner[2]);
@@ -306,8 +318,7 @@ struct PixelMap {
 // Grid is chunk*8 workgroups.  Returns 0: this lane has no pixel (whole workgroups past
 // numBlocks, or whole-frame lanes beyond the image edge); 1: march pixel (px,py) and store at
 // outIndex; 2: (tile mode) a compact-buffer slot outside the image: store background only.
-__device__ __forceinline__ int map_pixel(const PixelMap& m, uint32_t& px, uint32_t& py, int64_t& outIndex) {
-    uint32_t b = blockIdx.x;
+MRIRT_HD int map_pixel_at(const PixelMap& m, uint32_t b, uint32_t tid, uint32_t& px, uint32_t& py, int64_t& outIndex) {
     uint32_t logical;
     if (m.bandBlocks != 0) {
         // whole frame: horizontal bands of bandBlocks workgroups (a few packet rows) dealt round-robin
@@ -326,7 +337,7 @@ __device__ __forceinline__ int map_pixel(const PixelMap& m, uint32_t& px, uint32
         logical = (b % kXcds) * m.chunk + b / kXcds;     // one contiguous run per XCD
     }
     if (logical >= m.numBlocks) return 0;
-    uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    uint32_t wave = tid >> 6, lane = tid & 63u;
     uint32_t lx, ly;
     if (m.laneOrder == 0) {            // row-major 8x8: lane = x + 8y (the reference's thread group)
         lx = lane & 7u; ly = lane >> 3;
@@ -353,6 +364,9 @@ __device__ __forceinline__ int map_pixel(const PixelMap& m, uint32_t& px, uint32
     }
     return (px < m.width && py < m.height) ? 1 : 0;
 }
+__device__ __forceinline__ int map_pixel(const PixelMap& m, uint32_t& px, uint32_t& py, int64_t& outIndex) {
+    return map_pixel_at(m, blockIdx.x, threadIdx.x, px, py, outIndex);
+}
 
 // RGBA store, fp32 or the reference's rgba16_float
 template <bool HALF>
@@ -365,6 +379,12 @@ __device__ __forceinline__ void store_rgba(void* out, int64_t idx, float r, floa
         reinterpret_cast<float4*>(out)[idx] = make_float4(r, g, b, a);
     }
 }
+
+// Exact empty-space skipping: the scratch MrirtSkip::mask points at (mrirt_skip_mask_words 32-bit words) holds the macro
+// cells' bits as whole 64-lane ballots, then two byte maps of skip_map_stride(cells) bytes each (the empty-radius map, and
+// the scratch of its separable passes).
+MRIRT_HD uint32_t skip_bit_words(uint32_t cells) { return ((cells + 63u) / 64u) * 2u; }
+MRIRT_HD uint32_t skip_map_stride(uint32_t cells) { return (cells + 3u) & ~3u; }
 
 __device__ __forceinline__ void wave_count_add(uint64_t* counter, uint32_t v) {
 #pragma unroll

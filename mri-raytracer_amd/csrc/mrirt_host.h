@@ -24,6 +24,17 @@ inline int hip_fail(hipError_t e) {
         if (e_ != hipSuccess) return ::mrirt::hip_fail(e_);     \
     } while (0)
 
+// Process-environment switches exist only in development builds (-DMRIRT_DEBUG_ENV): the shipped library's behaviour is a
+// function of its arguments (getenv at every launch is invisible at the ABI and races with setenv).
+inline bool debug_env(const char* name) {
+#ifdef MRIRT_DEBUG_ENV
+    return getenv(name) != nullptr;
+#else
+    (void)name;
+    return false;
+#endif
+}
+
 // divisor + correctly rounded reciprocal for M<STRICT>::divu (Markstein); see mrirt_device.h
 inline UDiv make_udiv(float d) {
     UDiv u;
@@ -136,7 +147,7 @@ inline void fill_grid_dims(GridDims& g, const uint32_t dims[3], uint32_t layout)
 // lines: a 4 x 2 x 2-brick neighbourhood then spreads over 16 different sets.
 constexpr uint32_t kVgaSetLines = 64, kVgaRowPhase = 8, kVgaSlicePhase = 36;
 inline uint32_t vga_pad_to_phase(uint64_t lines, uint32_t phase) {
-    static const bool off = getenv("MRIRT_NO_STRIDE_PAD") != nullptr;      // A/B measurements (set before the first upload)
+    static const bool off = debug_env("MRIRT_NO_STRIDE_PAD");             // A/B measurements, development builds only
     if (off || lines < kVgaSetLines) return (uint32_t)lines;
     const uint32_t r = (uint32_t)(lines % kVgaSetLines);
     return (uint32_t)(lines + (phase + kVgaSetLines - r) % kVgaSetLines);

@@ -92,6 +92,20 @@ class PackedMLP:
     out_dim: int
 
 
+def with_flags(net: PackedMLP, no_weight_stationary: bool = False, no_refine: bool = False, mark_only: bool = False,
+               tie_sigmas: float = 0.0) -> PackedMLP:
+    """The same packed network (shared device buffers) with other ``MrirtInrDesc.flags`` / ``tieSigmas``: the A/B switches
+    of measurements and tests — the streaming kernel instead of the weight-stationary one, the bf16 pass without near-tie
+    marking and second pass, marking without the second pass, another mark width.  (ABI 2 read these from the process
+    environment at every launch.)"""
+    d = _lib.InrDesc()
+    C.memmove(C.byref(d), C.byref(net.desc), C.sizeof(d))
+    d.flags = ((_lib.INR_NO_WEIGHT_STATIONARY if no_weight_stationary else 0) | (_lib.INR_NO_REFINE if no_refine else 0)
+               | (_lib.INR_MARK_ONLY if mark_only else 0))
+    d.tieSigmas = float(tie_sigmas)
+    return PackedMLP(d, net.weights, net.biases, net.in_dim, net.out_dim)
+
+
 def _layers(params) -> List[Tuple[np.ndarray, np.ndarray]]:
     if isinstance(params, dict):                         # SIREN notebook layout: l0, l1, ...
         return [(np.asarray(params[f"l{i}"]["w"], np.float32), np.asarray(params[f"l{i}"]["b"], np.float32))

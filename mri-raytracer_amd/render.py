@@ -33,12 +33,24 @@ def _stream_ptr(stream) -> C.c_void_p:
     return C.c_void_p(s.cuda_stream if hasattr(s, "cuda_stream") else int(s))
 
 
+def _as_stream(stream) -> "torch.cuda.Stream":
+    """The launch stream as a torch stream object: None -> torch's current stream; a raw hipStream_t (integer) is adopted
+    as a ``torch.cuda.ExternalStream`` (torch does not own it), so that temporaries can be allocated on it too."""
+    if stream is None:
+        return torch.cuda.current_stream()
+    if isinstance(stream, torch.cuda.Stream):
+        return stream
+    return torch.cuda.ExternalStream(int(stream))
+
+
 def _on_stream(stream):
-    """Context that makes `stream` torch's current stream (allocations and host->device copies follow it);
-    a no-op for the default (None) and for raw hipStream_t integers, which torch cannot adopt without owning."""
-    if stream is not None and isinstance(stream, torch.cuda.Stream):
-        return torch.cuda.stream(stream)
-    return contextlib.nullcontext()
+    """Context that makes `stream` torch's current stream: every temporary of a call (uploads, the output, counters, the
+    skipping scratch) is then allocated ON the launch stream, which is what ties its lifetime to the work that uses it —
+    the caching allocator hands a freed block to a later allocation of the SAME stream only, i.e. behind the kernels
+    that still read it.  A no-op for the default (None)."""
+    if stream is None:
+        return contextlib.nullcontext()
+    return torch.cuda.stream(_as_stream(stream))
 
 
 def _ptr(t: Optional[torch.Tensor]) -> C.c_void_p:
@@ -257,72 +269,101 @@ def _bind_brats(params, intensities, labels, preds, ext, dev, pred_stream: bool 
 
 
 _last_skip_mask: Optional[torch.Tensor] = None
-_SKIP_MAPS: "collections.OrderedDict[tuple, torch.Tensor]" = collections.OrderedDict()
-_SKIP_MAPS_MAX = 8
 skip_map_builds = 0              # how many launches built a map (tests: a repeated frame must not)
+SKIP_MIN_EMPTY_FRACTION = 0.10   # of the 8^3 macro cells; below it skip=True renders with the plain kernels (same bits)
+_POPCOUNT = torch.tensor([bin(i).count("1") for i in range(256)], dtype=torch.int32)
 
 
-def _bind_skip(P, E, intensities, labels, preds, dev, stream):
-    """MrirtSkip for one call: the macro summaries of the bound Grid objects + the mask / empty-radius map scratch.
+class _SkipMap:
+    """One cached empty-radius map: the scratch tensor plus everything whose lifetime or identity the cache key rests on.
+
+    Lifetimes (VERDICT r3 #1a).  The key names the macro summaries by ``id()``; the entry HOLDS those tensors, so an id —
+    and the device address behind it — cannot be recycled while the key exists.  ``mask`` is allocated with the launch
+    stream current (``_on_stream``), so when an entry is evicted (or a call's temporaries go out of scope) while kernels
+    that read them are still queued, the caching allocator can hand the block only to a later allocation of the same
+    stream, which is ordered behind those kernels; nothing here is freed on the strength of the host's position in the
+    code.  ``built`` turns true only after the library reported that this launch marches with a map
+    (``mrirt_brats_skip_applicable``) and the launch that builds it was enqueued without error: a scratch that was never
+    written is never passed with ``mapReady``."""
+    __slots__ = ("mask", "held", "stream", "empty_fraction", "built")
+
+    def __init__(self, mask, held, stream):
+        self.mask, self.held, self.stream = mask, tuple(held), stream
+        self.empty_fraction: Optional[float] = None
+        self.built = False
+
+
+_SKIP_MAPS: "collections.OrderedDict[tuple, _SkipMap]" = collections.OrderedDict()
+_SKIP_MAPS_MAX = 8
+
+
+def _bind_skip(P, E, vp, lab, prd, intensities, labels, preds, dev, stream):
+    """MrirtSkip for one call, or (None, None, None) when this launch has no use for a map (it then goes out as the plain
+    render call and no scratch exists).  Returns (S, entry, hold): ``hold`` keeps every tensor S points at alive until the
+    caller drops it — after the launch has been enqueued, at the end of ``render_brats``.
 
     The map depends on the grids' summaries and on (dims, ww, wl, gamma, volEnabled, volWeight, showSeg, showPred, math) —
-    not on the camera — so a viewer's frames reuse it: scratches are cached per (those values, the bound summary
-    tensors, device, stream) and a hit sets ``mapReady`` (the library then skips the four pre-pass launches, ~30 us of
-    a 160 us viewer frame).  The stream is part of the key because the map was written by a launch on that stream and
-    nothing else orders a reader on another stream after it; the summary tensors are held by the entry, so a key can never
-    name freed-and-reused memory."""
+    not on the camera, and not on the layout / shading / kernel variant, which only decide WHETHER a launch marches with a
+    map (asked of the library per call, below) — so a viewer's frames reuse it: one entry per (those values, the bound
+    summary tensors, device, stream); a hit on a BUILT entry sets ``mapReady`` (the library then skips the four pre-pass
+    launches, ~30 us of a 160 us viewer frame).  The stream is part of the key because the map was written by a
+    launch on that stream and nothing else orders a reader on another stream after it."""
     global _last_skip_mask, skip_map_builds
+    lib = _lib.lib()
     S = _lib.Skip()
-    keep = []
+    hold = []
     for m in range(4):
         g = intensities[m] if m < len(intensities) else None
         if P.volEnabled[m] != 0:
             if not isinstance(g, Grid) or g.macro is None or g.macro.dtype != torch.float32:
                 raise ValueError(f"skip=True: gIntensity{m} must be a Grid made by upload_grid (it carries the macro-cell bounds)")
             S.macroUb[m] = g.macro.data_ptr()
-            keep.append(g.macro)
-    cells = isinstance(labels, Grid) and labels.layout == "labcell"      # one grid carries both summaries
-    for name, g, flag, which in (("macroSeg", labels, P.showSeg, "macro"), ("macroPred", labels if cells else preds, P.showPred, "macro2" if cells else "macro")):
+            hold.append(g.macro)
+    cells_grid = isinstance(labels, Grid) and labels.layout == "labcell"      # one grid carries both summaries
+    for name, g, flag, which in (("macroSeg", labels, P.showSeg, "macro"),
+                                 ("macroPred", labels if cells_grid else preds, P.showPred, "macro2" if cells_grid else "macro")):
         if flag != 0:
             m = getattr(g, which, None) if isinstance(g, Grid) else None
             if m is None or m.dtype != torch.int32:
                 raise ValueError("skip=True: a shown label grid must be a Grid made by upload_grid / upload_label_cells")
             setattr(S, name, m.data_ptr())
-            keep.append(m)
+            hold.append(m)
+    # does the library march this launch with a map at all?  (host-only query; < 0: the render call's own error)
+    rc = int(lib.mrirt_brats_skip_applicable(C.byref(P), C.byref(E), vp, _ptr(lab), _ptr(prd), C.byref(S)))
+    if rc < 0:
+        _lib.check(rc, "mrirt_brats_skip_applicable")
+    if rc == 0:
+        return None, None, None
     d = (C.c_uint32 * 3)(*[int(v) for v in P.dims])
-    words = int(_lib.lib().mrirt_skip_mask_words(d))
-    sid = stream if stream is not None else torch.cuda.current_stream()
-    sid = sid.cuda_stream if hasattr(sid, "cuda_stream") else int(sid)
+    words = int(lib.mrirt_skip_mask_words(d))
+    ts = _as_stream(stream)
     key = (tuple(int(v) for v in P.dims), float(P.ww), float(P.wl), float(P.gamma), tuple(int(v) for v in P.volEnabled),
            tuple(float(v) for v in P.volWeight), int(P.showSeg) != 0, int(P.showPred) != 0, int(E.math),
-           tuple(t.data_ptr() for t in keep), dev.index, sid)
-    hit = _SKIP_MAPS.get(key)
-    if hit is not None:
+           tuple(id(t) for t in hold), dev.index, int(ts.cuda_stream))
+    entry = _SKIP_MAPS.get(key)
+    if entry is not None and entry.built:
         _SKIP_MAPS.move_to_end(key)
-        mask, S.mapReady = hit[0], 1
-        if hit[2][0] is None:
+        S.mapReady = 1
+        if entry.empty_fraction is None:
             # second frame with this map: how much of the volume IS empty?  (One read-back per map, i.e. per change of window /
-            # weights / overlays — never per camera move.)  Where almost nothing can be skipped the skipping march only costs
-            # (a dense synthetic head: 0.161 vs 0.137 ms per viewer frame), so such maps switch it off for their lifetime.
-            cells = int(_lib.lib().mrirt_macro_cells(d))
-            bits = mask[: ((cells + 63) // 64) * 2].view(torch.uint8)
-            hit[2][0] = float(_POPCOUNT.to(dev)[bits.long()].sum().item()) / max(cells, 1)
-        if hit[2][0] < SKIP_MIN_EMPTY_FRACTION:
-            return None, None
+            # weights / overlays — never per camera move; it runs on the launch stream, behind the launch that built the map.)
+            # Where almost nothing can be skipped the skipping march only costs (a dense synthetic head: 0.161 vs 0.137 ms per
+            # viewer frame), so such maps switch it off for their lifetime.
+            cells = int(lib.mrirt_macro_cells(d))
+            bits = entry.mask[: ((cells + 63) // 64) * 2].view(torch.uint8)
+            entry.empty_fraction = float(_POPCOUNT.to(dev)[bits.long()].sum().item()) / max(cells, 1)
+        if entry.empty_fraction < SKIP_MIN_EMPTY_FRACTION:
+            return None, None, None
     else:
-        mask = torch.empty(words, dtype=torch.int32, device=dev)
-        _SKIP_MAPS[key] = (mask, list(keep), [None])    # holds the summaries: their addresses cannot be recycled under the key
-        while len(_SKIP_MAPS) > _SKIP_MAPS_MAX:
-            _SKIP_MAPS.popitem(last=False)
+        if entry is None:
+            entry = _SKIP_MAPS[key] = _SkipMap(torch.empty(words, dtype=torch.int32, device=dev), hold, ts)
+            while len(_SKIP_MAPS) > _SKIP_MAPS_MAX:
+                _SKIP_MAPS.popitem(last=False)          # (its tensors: see _SkipMap — stream-ordered by the allocator)
         skip_map_builds += 1
-    S.mask, S.maskWords = mask.data_ptr(), words
-    keep.append(mask)
-    _last_skip_mask = mask          # inspection hook (tests read the fraction of skippable cells)
-    return S, keep
-
-
-SKIP_MIN_EMPTY_FRACTION = 0.10   # of the 8^3 macro cells; below it skip=True renders with the plain kernels (same bits)
-_POPCOUNT = torch.tensor([bin(i).count("1") for i in range(256)], dtype=torch.int32)
+    S.mask, S.maskWords = entry.mask.data_ptr(), words
+    hold.append(entry.mask)
+    _last_skip_mask = entry.mask    # inspection hook (tests read the fraction of skippable cells)
+    return S, entry, hold
 
 
 def render_brats(params: Mapping[str, Any], intensities: Sequence[Optional[Union[ArrayLike, Grid]]],
@@ -350,14 +391,14 @@ def render_brats(params: Mapping[str, Any], intensities: Sequence[Optional[Union
         o, pitch = _alloc_out(int(P.imageSize[0]), int(P.imageSize[1]), E, dev, out)
         vp = (C.c_void_p * 4)(*[C.c_void_p(t.data_ptr()) if t is not None else None for t in vols])
         st = torch.zeros(2, dtype=torch.int64, device=dev) if stats else None
-        S = None
+        S = entry = hold = None
         if skip:
-            S, keep = _bind_skip(P, E, intensities, labels, preds, dev, stream)
+            S, entry, hold = _bind_skip(P, E, vp, lab, prd, intensities, labels, preds, dev, stream)
         if S is not None:
             rc = _lib.lib().mrirt_render_brats_skip(C.byref(P), C.byref(E), vp, _ptr(lab), _ptr(prd), C.byref(S), _ptr(o),
                                                     pitch, _ptr(st), _stream_ptr(stream))
             _lib.check(rc, "mrirt_render_brats_skip")
-            del keep
+            entry.built = True                      # the pre-pass is enqueued on the entry's stream: later frames may say mapReady
         else:
             rc = _lib.lib().mrirt_render_brats_ex(C.byref(P), C.byref(E), vp, _ptr(lab), _ptr(prd), _ptr(o),
                                                   pitch, _ptr(st), _stream_ptr(stream))
@@ -365,6 +406,7 @@ def render_brats(params: Mapping[str, Any], intensities: Sequence[Optional[Union
         if stats:
             s = st.cpu()
             return o, {"live_samples": int(s[0]), "shaded_samples": int(s[1])}
+        del hold                                    # (only here: every launch that reads these tensors has been enqueued)
     return o
 
 

@@ -1,0 +1,72 @@
+"""tools/check_async_loads.py is a correctness gate of the build (the pipelined march kernels issue their gathers as inline
+asm and retire them with hand-counted waits): its own regexes and data-flow are pinned here on canned listings, so a change of
+llvm-objdump's format or of the script cannot turn the gate into a silent pass."""
+import importlib.util
+import pathlib
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+spec = importlib.util.spec_from_file_location("check_async_loads", ROOT / "tools" / "check_async_loads.py")
+chk = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(chk)
+
+
+def listing(rows):
+    """rows of (instruction text, size in bytes) -> [(line number, objdump-style line)] at consecutive addresses"""
+    out, addr = [], 0x1000
+    for no, (text, size) in enumerate(rows):
+        words = " ".join(["DEADBEEF"] * (size // 4))
+        out.append((no, f"\t{text:<60} // {addr:012X}: {words}"))
+        addr += size
+    return out
+
+
+GOOD = [("global_load_dwordx4 v[0:3], v20, s[4:5]", 8), ("global_load_dwordx4 v[4:7], v21, s[4:5]", 8),
+        ("v_add_u32_e32 v22, v20, v21", 4),                       # touches neither destination
+        ("s_waitcnt vmcnt(1)", 4), ("v_add_f32_e32 v30, v0, v1", 4),   # the older gather has landed
+        ("s_waitcnt vmcnt(0)", 4), ("v_add_f32_e32 v31, v4, v5", 4), ("s_endpgm", 4)]
+
+
+def test_a_clean_listing_passes():
+    assert chk.check("k", listing(GOOD)) == []
+
+
+def test_a_read_before_the_wait_is_reported():
+    bad = list(GOOD)
+    bad[4], bad[3] = bad[3], bad[4]                               # the use of v0 moves above `vmcnt(1)`
+    found = chk.check("k", listing(bad))
+    assert len(found) == 1 and "v_add_f32_e32 v30, v0, v1" in found[0][1]
+
+
+def test_a_use_of_the_newer_gather_after_a_partial_wait_is_reported():
+    rows = GOOD[:4] + [("v_mov_b32_e32 v40, v6", 4)] + GOOD[4:]    # v[4:7] is still in flight after vmcnt(1)
+    found = chk.check("k", listing(rows))
+    assert [t for _, t in found] == ["v_mov_b32_e32 v40, v6"]
+
+
+def test_an_overwrite_and_an_address_use_of_an_inflight_destination_are_reported():
+    rows = [("global_load_dwordx2 v[8:9], v20, s[4:5]", 8), ("v_mov_b32_e32 v9, 0", 4),           # write
+            ("global_load_dword v10, v8, s[4:5]", 8),                                             # address register = a destination
+            ("s_waitcnt vmcnt(0)", 4), ("s_endpgm", 4)]
+    found = chk.check("k", listing(rows))
+    assert [t for _, t in found] == ["v_mov_b32_e32 v9, 0", "global_load_dword v10, v8, s[4:5]"]
+
+
+def test_a_violation_that_only_exists_around_the_loop_back_edge_is_reported():
+    # the gather at the bottom of the loop body is still in flight when the back edge reaches the read at the top
+    rows = [("s_waitcnt vmcnt(0)", 4),
+            ("v_add_f32_e32 v30, v0, v1", 4),                     # <- loop header: reads v[0:3]
+            ("global_load_dwordx4 v[0:3], v20, s[4:5]", 8),
+            ("s_cbranch_vccnz -4", 4),                            # back to the header: 4 bytes after this + (-4) * 4 = the v_add
+            ("s_waitcnt vmcnt(0)", 4), ("s_endpgm", 4)]
+    lst = listing(rows)
+    # target address = address after the branch + 4 * simm16; header is 3 instructions (16 bytes) back
+    found = chk.check("k", lst)
+    # (the re-issue into registers whose previous gather never got a wait is a second violation of the same loop)
+    assert [t for _, t in found] == ["v_add_f32_e32 v30, v0, v1", "global_load_dwordx4 v[0:3], v20, s[4:5]"]
+
+
+def test_the_tool_directory_comes_from_the_environment(monkeypatch, tmp_path):
+    for t in chk.TOOLS:
+        (tmp_path / t).write_text("")
+    monkeypatch.setenv("MRIRT_LLVM_BIN", str(tmp_path))
+    assert chk.llvm_bin() == tmp_path

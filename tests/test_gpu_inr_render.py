@@ -85,12 +85,8 @@ def test_c5_layers(setup, layout):
     assert (d <= 1e-4).mean() >= 0.995, (d <= 1e-4).mean()          # BASELINE's 1e-4 on >= 99.5 % of the pixels
     assert d.max() <= 0.25          # a flipped overlay step: alpha*T*|lut.rgb| with alpha = 1 - e^{-0.9*dt*1.5}
     # the same frame with the refinement switched off shows what it buys (and that the switch works)
-    import os
-    os.environ["MRIRT_INR_NO_REFINE"] = "1"
-    try:
-        raw, araw = mrirt.inr.render_brats_inr(p, grids, net, s["zmu"], s["zsg"], labels=gl, return_aux=True, one_pass=True)
-    finally:
-        del os.environ["MRIRT_INR_NO_REFINE"]
+    raw, araw = mrirt.inr.render_brats_inr(p, grids, mrirt.inr.with_flags(net, no_refine=True), s["zmu"], s["zsg"], labels=gl,
+                                           return_aux=True, one_pass=True)
     agree_raw = araw["classes"].cpu().numpy() == want
     assert agree_raw.mean() < agree.mean() and agree_raw.mean() >= 0.99
 

@@ -164,11 +164,10 @@ def test_skip_with_several_shaded_modalities_rolling_kernel(layout, channels, ma
     a = mrirt.render_brats(q, grids, labels=labels, ext=ext)
     b = mrirt.render_brats(q, grids, labels=labels, ext=ext, skip=True)
     assert torch.equal(a, b)
-    raw = render._last_skip_mask
-    raw.fill_(0x5a5a5a5a)
     render._SKIP_MAPS.clear()
+    builds = render.skip_map_builds
     mrirt.render_brats(q, grids, labels=labels, ext=ext, skip=True)
-    assert int((render._last_skip_mask != 0x5a5a5a5a).sum()) == 0 or render._last_skip_mask is not raw
+    assert len(render._SKIP_MAPS) == 0 and render.skip_map_builds == builds, "no map, no scratch, no cache entry (ADVICE r3)"
 
 
 def test_skip_switches_itself_off_on_a_volume_without_empty_space():
@@ -186,7 +185,7 @@ def test_skip_switches_itself_off_on_a_volume_without_empty_space():
     frames = [mrirt.render_brats(p, [g], skip=True) for _ in range(3)]
     assert all(torch.equal(f, plain) for f in frames)
     (entry,) = render._SKIP_MAPS.values()
-    assert entry[2][0] is not None and entry[2][0] < render.SKIP_MIN_EMPTY_FRACTION
+    assert entry.built and entry.empty_fraction is not None and entry.empty_fraction < render.SKIP_MIN_EMPTY_FRACTION
 
 
 def test_skip_with_tile_sharding():

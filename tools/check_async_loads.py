@@ -141,14 +141,40 @@ def check(name, lines):
     return bad
 
 
-LLVM = pathlib.Path("/opt/rocm/lib/llvm/bin")
+TOOLS = ("llvm-objcopy", "clang-offload-bundler", "llvm-objdump")
 MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
+
+
+class ToolsMissing(RuntimeError):
+    pass
+
+
+def llvm_bin() -> pathlib.Path:
+    """The ROCm LLVM tool directory of the compiler that built the library: $MRIRT_LLVM_BIN, else next to $HIPCC
+    (<rocm>/bin/hipcc -> <rocm>/lib/llvm/bin), else $ROCM_PATH, else /opt/rocm."""
+    import os
+    import shutil
+    cands = []
+    if os.environ.get("MRIRT_LLVM_BIN"):
+        cands.append(pathlib.Path(os.environ["MRIRT_LLVM_BIN"]))
+    hipcc = os.environ.get("HIPCC") or shutil.which("hipcc")
+    if hipcc:
+        cands.append(pathlib.Path(hipcc).resolve().parent.parent / "lib" / "llvm" / "bin")
+    if os.environ.get("ROCM_PATH"):
+        cands.append(pathlib.Path(os.environ["ROCM_PATH"]) / "lib" / "llvm" / "bin")
+    cands.append(pathlib.Path("/opt/rocm/lib/llvm/bin"))
+    for c in cands:
+        if all((c / t).exists() for t in TOOLS):
+            return c
+    raise ToolsMissing("check_async_loads: need " + ", ".join(TOOLS) + " of the ROCm LLVM that built the library; looked in "
+                       + ", ".join(str(c) for c in cands) + " — set MRIRT_LLVM_BIN to the directory that holds them")
 
 
 def device_disassembly(so: pathlib.Path) -> str:
     """gfx950 disassembly of every code object embedded in the library: the .hip_fatbin section holds one offload bundle per
     HIP source; each is unbundled and disassembled."""
     import tempfile
+    LLVM = llvm_bin()
     out = []
     with tempfile.TemporaryDirectory() as td:
         td = pathlib.Path(td)
@@ -170,7 +196,11 @@ def device_disassembly(so: pathlib.Path) -> str:
 
 def main():
     so = pathlib.Path(sys.argv[1]) if len(sys.argv) > 1 else ROOT / "mri-raytracer_amd" / "libmrirt.so"
-    text = device_disassembly(so)
+    try:
+        text = device_disassembly(so)
+    except ToolsMissing as e:
+        print(e)
+        return 3
     if "s_endpgm" not in text or "brats_march_pipe_kernel" not in text:
         print(f"{so}: no device disassembly of brats_march_pipe_kernel found")
         return 2

@@ -2,7 +2,7 @@
 """Near-tie refinement, measured: per network — calibration record, fraction of points marked, argmax agreement with
 an fp64 evaluation before / after refinement, error of the split-bf16 logits, and the cost of the extra pass.
     python3 tools/inr_refine_check.py [n_points] > profiles/r03_inr_refine.txt
-MRIRT_INR_TIE_SIGMAS (default 3) and MRIRT_INR_NO_REFINE are read by the library at every launch."""
+The mark width and the no-refinement switch travel in MrirtInrDesc.tieSigmas / .flags (inr.with_flags)."""
 import math, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -52,11 +52,10 @@ def study(name, net, coords, feats, want):
     n = f.shape[0]
     print(f"== {name}: n={n}, logit range {scale:.3f}; calibration rms {cal['rms_error']:.3e} (= {cal['rms_error'] / scale:.2e} of range), "
           f"max {cal['max_error']:.3e}, max|logit| on the calibration set {cal['max_logit']:.3f}")
-    os.environ["MRIRT_INR_NO_REFINE"] = "1"
-    lg, a0 = inr._forward(net, c, f, n, True, True)
+    raw = inr.with_flags(net, no_refine=True)
+    lg, a0 = inr._forward(raw, c, f, n, True, True)
     a0 = a0.cpu().numpy(); lg = lg.cpu().numpy().astype(np.float64)
-    t0 = timed(lambda: inr._forward(net, c, f, n, False, True))
-    del os.environ["MRIRT_INR_NO_REFINE"]
+    t0 = timed(lambda: inr._forward(raw, c, f, n, False, True))
     srt = np.sort(lg, 1)
     gap = srt[:, -1] - srt[:, -2]
     print(f"   bf16 pass: max|dlogit| {np.abs(lg - want).max() / scale:.2e} of range, rms {np.sqrt(((lg - want) ** 2).mean()) / scale:.2e}; "
@@ -67,15 +66,14 @@ def study(name, net, coords, feats, want):
     print(f"   split-bf16 pass on every point: max|dlogit| {np.abs(lr - want).max() / scale:.2e} of range; agreement {np.mean(ar == wa):.6f} "
           f"({int((ar != wa).sum())} flips); {tr:.3f} ms")
     for sig in (2.0, 2.5, 3.0, 4.0, 5.0):
-        os.environ["MRIRT_INR_TIE_SIGMAS"] = str(sig)
-        _, a1 = inr._forward(net, c, f, n, False, True)
+        wide = inr.with_flags(net, tie_sigmas=sig)
+        _, a1 = inr._forward(wide, c, f, n, False, True)
         a1 = a1.cpu().numpy()
         marked = np.mean(gap < sig * math.sqrt(2) * cal["rms_error"])
-        t1 = timed(lambda: inr._forward(net, c, f, n, False, True))
+        t1 = timed(lambda: inr._forward(wide, c, f, n, False, True))
         assert (a1 & 0x4000).sum() == 0
         print(f"   sigmas {sig:3.1f}: marked {marked:.4f} of the points; agreement {np.mean(a1 == wa):.6f} ({int((a1 != wa).sum())} flips); "
               f"bf16 + refinement {t1:.3f} ms (+{(t1 - t0) / t0 * 100:.1f} %)")
-    del os.environ["MRIRT_INR_TIE_SIGMAS"]
 
 
 coords = (rng.random((N, 3)) * 2 - 1).astype(np.float32)
