@@ -78,6 +78,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-inr", action="store_true", help="skip the INR (MFMA) side measurement")
     ap.add_argument("--no-k1", action="store_true", help="skip the config-2 (reference K1 semantics) side measurement")
+    ap.add_argument("--no-scaling-model", action="store_true", help="N=1: skip the one-GPU emulation of the 1/2/4/8-rank tile shares")
     ap.add_argument("--force-exchange", action="store_true",
                     help="N=1 only: still create the RCCL group (world size 1), render compact tiles and run the "
                          "asynchronous gather + de-tiling path — a single-GPU rehearsal of the N>1 code")
@@ -326,10 +327,14 @@ def cpu_baseline(params, vol, ext, rows, n_image):
     okeys = ("cameraMode", "orthoHalfHeight", "shadeMode", "ka", "kd", "ks", "specPow2", "gradEps")
     oext = {k: v for k, v in ext.items() if k in okeys}
 
+    last = {}
+
     def run(r0, r1):
         t = time.perf_counter()
-        _, aux = oracle_c.brats_main(params, [vol], None, None, oext, return_aux=True, rows=(r0, r1))
-        return aux["live_samples"], time.perf_counter() - t
+        img, aux = oracle_c.brats_main(params, [vol], None, None, oext, return_aux=True, rows=(r0, r1))
+        dt = time.perf_counter() - t
+        last.update(frame=img, rows=(r0, r1), live=aux["live_samples"])
+        return aux["live_samples"], dt
 
     mid = n_image // 2
     if rows <= 0:      # calibrate on 16 central rows, then size the sample for ~12 s of wall time
@@ -351,7 +356,84 @@ def cpu_baseline(params, vol, ext, rows, n_image):
         cpu_model = "unknown CPU"
     return {"value": round(live / dt / 1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
             "sample": f"rows {r0}..{r1 - 1} of the same {n_image}x{n_image} frame x {reps} pass(es) "
-                      f"({live} live samples in {dt:.1f} s; C/OpenMP oracle oracle/oracle_c.c, {cores} threads on {cpu_model})"}
+                      f"({live} live samples in {dt:.1f} s; C/OpenMP oracle oracle/oracle_c.c, {cores} threads on {cpu_model})"}, last
+
+
+def parity_block(gpu_frame, gpu_live, oracle_band, n_image):
+    """The frame the timed kernel renders against the oracle rows the CPU leg has just rendered: the same
+    synthetic volume, camera and transfer function; STRICT math is held to bit equality in the tests, the tolerance
+    BASELINE.json states is 1e-4 max-abs.  ``live_equal`` compares the kernel's own live-sample counter with the
+    oracle's when the band is the whole frame (a band has no GPU-side counter of its own)."""
+    r0, r1 = oracle_band["rows"]
+    ref = oracle_band["frame"]
+    got = gpu_frame[r0:r1].cpu().numpy()
+    err = float(np.abs(got - ref).max())
+    whole = r0 == 0 and r1 == n_image
+    return {"against": "oracle/oracle_c.c (CPU restatement of inr/viewer/brats_rt.slang:85-168 + the build-defined gradient shading), "
+                       "rendered in this run on the host", "rows": int(r1 - r0), "row_range": [int(r0), int(r1)],
+            "max_abs_err": err, "bit_identical": bool(np.array_equal(got, ref)), "tolerance": 1e-4,
+            "live_equal": (int(gpu_live) == int(oracle_band["live"])) if whole else None,
+            "live_samples_oracle": int(oracle_band["live"]) if whole else None}
+
+
+def scaling_model(dev, grid, n, march_steps, ext, tile, alpha, reps=10):
+    """What ONE GPU can say about 1 -> 8 scaling, clearly an emulation: BASELINE config 4
+    (2048^2 px of the same volume) cut into `tile`^2 tiles dealt round-robin; for N = 1, 2, 4, 8 EVERY rank's share is
+    rendered on this GPU (HIP events, `reps` launches each) and the slowest rank is what an N-GPU frame would wait for.
+    ``pct_of_linear`` = share(1) / (N x share(N)).  The exchange is modelled, not measured: each peer's compact tiles
+    cross its own xGMI link to the root once (MI355X_MICROARCH.md: 7 links x ~153 GB/s per GPU; 0.75 of that assumed for a
+    single RCCL gather), in parallel over the links, and overlap the next frame's march; the root's de-tiling kernel and
+    local copy are measured here."""
+    import torch
+    import mrirt
+    from mrirt import synth, tiles
+    image = 2048
+    p = synth.brats_scene(n, image, march_steps, channels=1, intensity_alpha=alpha)
+    share, worst_rank, live_max = {}, {}, {}
+    for world in (1, 2, 4, 8):
+        times = []
+        for r in range(world):
+            e = tiles.shard_ext(ext, r, world, tile)
+            out = mrirt.render_brats(p, [grid], ext=e)
+            mrirt.render_brats(p, [grid], out=out, ext=e)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                mrirt.render_brats(p, [grid], out=out, ext=e)
+            e1.record()
+            torch.cuda.synchronize()
+            times.append(e0.elapsed_time(e1) / reps)
+            del out
+        share[world] = max(times)
+        worst_rank[world] = int(np.argmax(times))
+    # the root's part of the exchange: local copy of its own tiles + the de-tiling kernel over the gathered buffer
+    world = 8
+    max_local = tiles.local_tile_count(image, image, tile, 0, world)
+    gathered = torch.zeros((world, max_local, tile, tile, 4), device=dev)
+    frame = torch.empty((image, image, 4), device=dev)
+    for _ in range(2):
+        mrirt.detile(gathered, image, image, tile, world, out=frame)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        mrirt.detile(gathered, image, image, tile, world, out=frame)
+    e1.record()
+    torch.cuda.synchronize()
+    detile_ms = e0.elapsed_time(e1) / reps
+    link_gbs, eff = 153.0, 0.75
+    wire = {w: (0.0 if w == 1 else tiles.local_tile_count(image, image, tile, 0, w) * tile * tile * 16 / (link_gbs * eff * 1e9) * 1e3)
+            for w in (1, 2, 4, 8)}
+    return {"emulated_on_one_gpu": True,
+            "workload": f"C4: {n}^3 volume, {image}x{image} px, {march_steps} steps/ray, {tile}x{tile} tiles round-robin; every rank's share "
+                        "rendered on this one GPU, slowest rank per world size",
+            "share_ms": {str(w): round(share[w], 4) for w in share}, "slowest_rank": {str(w): worst_rank[w] for w in worst_rank},
+            "pct_of_linear": {str(w): round(100.0 * share[1] / (w * share[w]), 1) for w in share},
+            "exchange_wire_ms_model": {str(w): round(wire[w], 4) for w in wire},
+            "exchange_model": f"per peer: its compact tiles over one xGMI link at {link_gbs} GB/s x {eff} (assumed), peers in parallel; "
+                              "asynchronous: overlaps the next frame's march (FrameExchange)",
+            "root_detile_ms": round(detile_ms, 4),
+            "modelled_frame_ms": {str(w): round(max(share[w], wire[w] + (detile_ms if w > 1 else 0.0)), 4) for w in share},
+            "note": "NOT a multi-GPU measurement: bench.py --gpus N on an N-GPU node measures the real thing (RCCL gather, all ranks)"}
 
 
 def main():
@@ -496,6 +578,18 @@ def main():
         traffic, on_chip, note = measured_traffic(key) if profiled else (None, None, "not a profiled configuration")
         hbm_bytes = traffic if traffic is not None else compulsory
         achieved = hbm_bytes / (kernel_ms * 1e-3) / 1e9
+        # The roof that binds this kernel: every live sample's taps — 8 x 16 B shaded, 2 x 16 B
+        # on QUAD grids — have to reach a lane's registers through the texture data-return path, 64 B per clock per CU.  With
+        # the clock the part held under the profiler this is the time the return path alone needs, as a fraction of the
+        # kernel's time; HBM is NOT the limiter (its fraction is the line's `frac`, kept because the metric names it).
+        tap_bytes = (8 if not a.no_shade else 2) * 16 if a.layout in ("vg", "vga", "quad") else 8 * 4 * (7 if not a.no_shade else 1)
+        if on_chip is not None and on_chip.get("effective_clock_ghz"):
+            on_chip = dict(on_chip)
+            floor_ms = my_live * tap_bytes / (64.0 * 256 * on_chip["effective_clock_ghz"] * 1e9) * 1e3
+            on_chip["td_return_frac"] = round(floor_ms / kernel_ms, 4)
+            on_chip["td_return_floor_ms"] = round(floor_ms, 4)
+            on_chip["td_return_basis"] = (f"{my_live} live samples x {tap_bytes} B of taps / (64 B/clk/CU x 256 CUs x {on_chip['effective_clock_ghz']} GHz "
+                                          "held under the profiler) / kernel time")
         out = {
             "metric": "live Msamples/s, 512^3 fp32 volume @ 1024^2 x 512 steps (gradient shading + ERT)"
                       + ("" if image == 1024 else f" [this run: {image}^2]"),
@@ -517,8 +611,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic,
-                         "basis": ("rocprofv3 PMC HBM bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE), " + str(note)) if traffic is not None
-                                  else ("compulsory bytes (volume once + framebuffer): a floor of the real traffic; " + str(note)),
+                         "basis": (("rocprofv3 PMC HBM bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE), " + str(note)) if traffic is not None
+                                   else ("compulsory bytes (volume once + framebuffer): a floor of the real traffic; " + str(note)))
+                                  + "; HBM is not what limits this kernel: see on_chip.td_return_frac (the texture data-return path) and l1_hit_rate",
                          # what actually binds the kernel (PMC passes): its gathers are served by L1/L2
                          "on_chip": on_chip,
                          "kernel": "brats_march_pipe_kernel" if not a.variant & 4 else "brats_march_kernel", "kernel_ms": round(kernel_ms, 4),
@@ -535,8 +630,14 @@ def main():
             out["k1_reference_path"] = k1_reference_path(dev)
         if world == 1 and not a.no_inr:
             out["inr_path"] = inr_path(dev)
+        if world == 1 and not a.no_scaling_model and not a.no_shade and not a.force_exchange:
+            out["scaling_model"] = scaling_model(dev, grid, n, a.march_steps, ext, a.tile, a.alpha)
         if not a.no_cpu_baseline and a.cpu_rows != 0 and world == 1:
-            out["cpu_baseline"] = cpu_baseline(params, vol, ext, min(a.cpu_rows, image), image)
+            out["cpu_baseline"], band = cpu_baseline(params, vol, ext, min(a.cpu_rows, image), image)
+            if not grouped:
+                # the frame of the timed configuration, rendered once more (untimed) and held to the oracle's rows
+                frame, stp = mrirt.render_brats(params, [grid], ext=ext, stats=True)
+                out["parity"] = parity_block(frame, stp["live_samples"], band, image)
         print(json.dumps(out), flush=True)
     if grouped:
         dist.destroy_process_group()

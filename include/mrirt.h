@@ -276,6 +276,18 @@ int mrirt_render_brats_skip(const MrirtBratsParams* params, const MrirtRenderExt
  * as holding one.  < 0: the MrirtStatus the render call would return for these arguments.                               */
 int mrirt_brats_skip_applicable(const MrirtBratsParams* params, const MrirtRenderExt* ext, const void* const vol[4],
                                 const void* labels, const void* preds, const MrirtSkip* skip);
+/* Host-only query, nothing is launched: which march kernel family mrirt_render_brats_skip (skip != NULL) / mrirt_render_brats_ex
+ * (skip == NULL) takes for these arguments — the generic kernel (any layout, 64-bit offsets: grids >= 4 GiB, label grids
+ * >= 2^30 elements, BRICK), the software-pipelined one, the rolling one (2-4 shaded modalities), or the opt-in LDS kernels —
+ * with MRIRT_KERNEL_SKIPPING / MRIRT_KERNEL_LABEL_CELLS or'ed in.  MRIRT_KERNEL_NONE: a rank that owns no tile.
+ * < 0: the MrirtStatus the render call would return.  (Tests and the bench line name the kernel they measured with it.)  */
+typedef enum MrirtKernelFamily {
+    MRIRT_KERNEL_NONE = 0, MRIRT_KERNEL_GENERIC = 1, MRIRT_KERNEL_PIPELINED = 2, MRIRT_KERNEL_ROLLING = 3,
+    MRIRT_KERNEL_SLAB = 4, MRIRT_KERNEL_RING = 5,
+    MRIRT_KERNEL_SKIPPING = 16, MRIRT_KERNEL_LABEL_CELLS = 32
+} MrirtKernelFamily;
+int mrirt_brats_kernel_family(const MrirtBratsParams* params, const MrirtRenderExt* ext, const void* const vol[4],
+                              const void* labels, const void* preds, const MrirtSkip* skip);
 
 /* ------------------------------------------------------------------------------------ */
 /* number of tiles rank `rank` of `world` renders for a W x H image */

@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     "mrirt_build_macro_max", "mrirt_build_macro_labels", "mrirt_render_brats_skip", "mrirt_render_volume", "mrirt_build_cell8", "mrirt_render_sdf", "mrirt_tiles_for_rank",
     "mrirt_detile", "mrirt_inr_pack_bytes", "mrirt_inr_pack_weights", "mrirt_inr_calibrate", "mrirt_inr_forward", "mrirt_inr_forward_refined",
     "mrirt_inr_predict_volume", "mrirt_abi_version", "mrirt_status_string", "mrirt_last_hip_error",
-    "mrirt_sizeof", "mrirt_brats_skip_applicable", "mrirt_install_abort_trace",
+    "mrirt_sizeof", "mrirt_brats_skip_applicable", "mrirt_brats_kernel_family", "mrirt_install_abort_trace",
 ]
 
 ABI_VERSION = 3          # MRIRT_ABI_VERSION of include/mrirt.h this binding was written against
@@ -39,6 +39,8 @@ OUT_RGBA32F, OUT_RGBA16F = 0, 1
 VOX_U32X4, VOX_U8, VOX_F32, VOX_CELL8 = 0, 1, 2, 3
 INR_FOURIER_RELU, INR_SIREN = 0, 1
 INR_NO_WEIGHT_STATIONARY, INR_NO_REFINE, INR_MARK_ONLY = 1, 2, 4      # MrirtInrFlags
+KERNEL_NONE, KERNEL_GENERIC, KERNEL_PIPELINED, KERNEL_ROLLING, KERNEL_SLAB, KERNEL_RING = 0, 1, 2, 3, 4, 5   # MrirtKernelFamily
+KERNEL_SKIPPING, KERNEL_LABEL_CELLS = 16, 32
 
 f32, u32 = C.c_float, C.c_uint32
 
@@ -270,6 +272,8 @@ def lib() -> C.CDLL:
     l.mrirt_render_brats_skip.restype = i32
     l.mrirt_brats_skip_applicable.argtypes = [C.POINTER(BratsParams), C.POINTER(RenderExt), C.POINTER(vp), vp, vp, C.POINTER(Skip)]
     l.mrirt_brats_skip_applicable.restype = i32
+    l.mrirt_brats_kernel_family.argtypes = l.mrirt_brats_skip_applicable.argtypes
+    l.mrirt_brats_kernel_family.restype = i32
     l.mrirt_install_abort_trace.argtypes = [i32]
     l.mrirt_install_abort_trace.restype = i32
     l.mrirt_build_cell8.argtypes = [vp, u32, C.POINTER(u32), vp, vp]

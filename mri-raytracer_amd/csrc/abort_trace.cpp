@@ -35,7 +35,7 @@ void on_abort(int sig, siginfo_t* info, void* ctx) {
         struct stat st;
         if (fstat(2, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
             put("==== tail of the redirected stderr (fd 2 is a regular file) ====\n");
-            static char buf[16384];
+            static char buf[65536];
             const off_t want = st.st_size < (off_t)sizeof buf ? st.st_size : (off_t)sizeof buf;
             const ssize_t got = pread(2, buf, (size_t)want, st.st_size - want);
             if (got > 0) (void)!write(g_fd, buf, (size_t)got);

@@ -103,15 +103,30 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // (1) the destination is live from the asm to its uses, so the allocator cannot hand the register to anything else while
 // the load is in flight; (2) nothing may READ it before arrive() — tools/check_async_loads.py scans the built library's
 // disassembly for a read (or a copy / spill) of a gather destination between the gather and its wait and fails the build
-// check if there is one; (3) every other vector-memory operation of these kernels (frame store, counters) comes after the loop.
+// check if there is one; (3) every other vector-memory operation of these kernels (frame store, counters) comes after the loop;
+// (4) THE BASE POINTER IS RE-MATERIALISED BY A SCALAR MOVE INSIDE THE ASM STATEMENT.  gfx9 has a hazard the hardware does not
+// interlock: a vector-memory instruction that reads an SGPR needs five wait states after a VALU instruction wrote that
+// SGPR.  The compiler inserts the s_nops for loads it knows — not for inline asm (LLVM's hazard recogniser: "doesn't attempt
+// to address all possible inline asm hazards").  Under SGPR pressure it keeps a modality's base pointer spilled in VGPR
+// lanes and restores it with v_readlane_b32 — a VALU write of an SGPR — right in front of the gather: two wait states
+// instead of five in brats_march_pipe_kernel<strict, QUAD, 3 modalities, labels>, whose gathers then could read the
+// register's PREVIOUS content as the high half of their address — the one unexplained memory-access fault of rounds 3 and 4
+// (tests/test_gpu_skip.py::test_skip_is_bit_identical[strict-quad-False-3]).  An s_mov_b64 is a scalar
+// instruction: its read of a VALU-written SGPR is interlocked, and the gather's read of an SALU-written SGPR has no
+// hazard, so the copy is the cheapest sound form (one SALU instruction per gather, no stall).  tools/check_async_loads.py
+// now also scans EVERY kernel of the library for the hazard itself (a VALU write of an SGPR fewer than five wait states in
+// front of a vector-memory instruction that reads it) and fails the build on a hit.
+typedef uint64_t sbase_t;
 __device__ __forceinline__ void async_load_vec4(float4& dst, const void* __restrict__ base, uint32_t elem) {
     f32x4 t;
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(t) : "v"(elem << 4), "s"(base));
+    sbase_t b;
+    asm volatile("s_mov_b64 %1, %3\n\tglobal_load_dwordx4 %0, %2, %1" : "=v"(t), "=&s"(b) : "v"(elem << 4), "s"(base));
     dst = __builtin_bit_cast(float4, t);
 }
 __device__ __forceinline__ void async_load_u32(uint32_t& dst, const void* __restrict__ base, uint32_t byteOff) {
     uint32_t t;
-    asm volatile("global_load_dword %0, %1, %2" : "=v"(t) : "v"(byteOff), "s"(base));
+    sbase_t b;
+    asm volatile("s_mov_b64 %1, %3\n\tglobal_load_dword %0, %2, %1" : "=v"(t), "=&s"(b) : "v"(byteOff), "s"(base));
     dst = t;
 }
 
@@ -288,13 +303,15 @@ template <> struct Taps<0, true> : TapsScalar<0, true> {};
 // (async_load_pair) and retire a whole stage with one wait, like the float4 layouts.
 __device__ __forceinline__ void async_load_pair(f32x2& dst, const void* __restrict__ base, uint32_t byteOff) {
     f32x2 t;
-    asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(t) : "v"(byteOff), "s"(base));
+    sbase_t b;                                        // (the base through a scalar move: see async_load_vec4, point 4)
+    asm volatile("s_mov_b64 %1, %3\n\tglobal_load_dwordx2 %0, %2, %1" : "=v"(t), "=&s"(b) : "v"(byteOff), "s"(base));
     dst = t;
 }
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void async_load_words2(u32x2& dst, const void* __restrict__ base, uint32_t byteOff) {     // (label cells)
     u32x2 t;
-    asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(t) : "v"(byteOff), "s"(base));
+    sbase_t b;
+    asm volatile("s_mov_b64 %1, %3\n\tglobal_load_dwordx2 %0, %2, %1" : "=v"(t), "=&s"(b) : "v"(byteOff), "s"(base));
     dst = t;
 }
 template <> struct Taps<0, false> {
@@ -390,8 +407,8 @@ __device__ __forceinline__ void composite(const K1Args& a, const float rd[3], co
                                           RayState& r, const float4* lutS = nullptr) {
     using Mm = M<STRICT>;
     // wSum (brats_rt.slang:123-130) is the same for every sample: summed on the host
-    if (a.wsum.d > 0.0f && a.wsum.d != 1.0f) v = Mm::divu(v, a.wsum);      // x / 1 == x: skip the three instructions
-    float val = satf(Mm::divu(v - a.tfLo, a.wwDiv));                 // :132
+    if (a.wsum.d > 0.0f && a.wsum.d != 1.0f) v = Mm::divu_data(v, a.wsum);      // x / 1 == x: skip the three instructions
+    float val = satf(Mm::divu_data(v - a.tfLo, a.wwDiv));                 // :132
     if constexpr (!GAMMA1) val = Mm::pow(val, a.gamma);              // :133
     ++r.nLive;
     if (val > 0.0f) {

@@ -580,11 +580,16 @@ __global__ __launch_bounds__(256, 2) void brats_march_roll_kernel(const K1Args a
     finish(a, kind, oidx, r);
 }
 
+// mrirt_brats_kernel_family: when set, the launchers record which kernel family they WOULD launch and launch nothing
+thread_local int* g_family_probe = nullptr;
+
 template <bool STRICT, int LAYOUT, bool SHADE, int NCH>
 static int launch_roll(const K1Args& a, hipStream_t s) {
     const dim3 grid(a.map.chunk * kXcds), block(a.map.blockPx == 8 ? 64 : 256);
     const bool overlays = a.showSeg != 0 || a.showPred != 0;
-    if (a.skipDist != nullptr && !overlays && (!STRICT || a.gamma == 1.0f)) {      // (mrirt_render_brats_skip builds the map only then)
+    const bool skipKernel = a.skipDist != nullptr && !overlays && (!STRICT || a.gamma == 1.0f);      // (mrirt_render_brats_skip builds the map only then)
+    if (g_family_probe != nullptr) { *g_family_probe = MRIRT_KERNEL_ROLLING | (skipKernel ? MRIRT_KERNEL_SKIPPING : 0); return MRIRT_OK; }
+    if (skipKernel) {
         hipLaunchKernelGGL((brats_march_roll_kernel<STRICT, LAYOUT, SHADE, NCH, STRICT, false, true>), grid, block, 0, s, a);
     } else if (STRICT && a.gamma == 1.0f) {
         if (overlays) hipLaunchKernelGGL((brats_march_roll_kernel<STRICT, LAYOUT, SHADE, NCH, STRICT, true>), grid, block, 0, s, a);
@@ -606,8 +611,14 @@ static int launch_pipe(const K1Args& a, hipStream_t s) {
     // (LINEAR grids have no skipping kernels: mrirt_render_brats_skip never builds a map for them)
     constexpr bool kHasSkip = LAYOUT != 0;
     const bool skip = kHasSkip && a.skipDist != nullptr;
+    const bool cellsKernel = LAYOUT == 3 && a.labCell != nullptr && overlays && !skip;      // label cells: the plain pipelined kernel with one label gather
+    const bool skipKernel = skip && (!STRICT || a.gamma == 1.0f);
+    if (g_family_probe != nullptr) {
+        *g_family_probe = MRIRT_KERNEL_PIPELINED | (skipKernel ? MRIRT_KERNEL_SKIPPING : 0) | (cellsKernel ? MRIRT_KERNEL_LABEL_CELLS : 0);
+        return MRIRT_OK;
+    }
     if constexpr (LAYOUT == 3) {
-        if (a.labCell != nullptr && overlays && !skip) {                 // label cells: the plain pipelined kernel with one label gather
+        if (cellsKernel) {
             if (STRICT && a.gamma == 1.0f) hipLaunchKernelGGL((brats_march_pipe_kernel<STRICT, LAYOUT, SHADE, NCH, STRICT, true, false, true>), grid, block, 0, s, a);
             else                           hipLaunchKernelGGL((brats_march_pipe_kernel<STRICT, LAYOUT, SHADE, NCH, false, true, false, true>), grid, block, 0, s, a);
             MRIRT_HIP(hipGetLastError());
@@ -678,6 +689,7 @@ static int launch(const K1Args& a, bool pipeAsked, hipStream_t s) {
             }
         }
     }
+    if (g_family_probe != nullptr) { *g_family_probe = MRIRT_KERNEL_GENERIC; return MRIRT_OK; }
     const dim3 grid(a.map.chunk * kXcds), block(a.map.blockPx == 8 ? 64 : 256);
     hipLaunchKernelGGL((brats_march_kernel<STRICT, LAYOUT, SHADE>), grid, block, 0, s, a);
     MRIRT_HIP(hipGetLastError());
@@ -736,7 +748,7 @@ __device__ __forceinline__ void emit_row(const K1Args& a, const EmitArgs& e, con
     for (int m = 0; m < 4; ++m) {
         taps[m].template eval<STRICT>(s, sv[m], nullptr);
         const float v = sv[m];
-        z[m] = STRICT ? Mm::divu(v - e.zmu[m], e.zsigma[m]) : (v - e.zmu[m]) * e.zsigma[m].r;
+        z[m] = STRICT ? Mm::divu_data(v - e.zmu[m], e.zsigma[m]) : (v - e.zmu[m]) * e.zsigma[m].r;
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {    // fp64, one rounding: predict_volume's coordinate at lattice points
@@ -1118,7 +1130,7 @@ __global__ __launch_bounds__(256) void skip_mask_kernel(const SkipArgs k) {
     if (cell < k.cells) {
         float v = 0.0f;
         for (uint32_t c = 0; c < k.nch; ++c) v = Mm::mad(k.ub[c][cell], k.w[c], v);
-        if (k.wsum.d > 0.0f) v = Mm::divu(v, k.wsum);
+        if (k.wsum.d > 0.0f) v = Mm::divu_data(v, k.wsum);
         empty = v <= k.tfLo;                                         // NaN / inf bounds: not empty
         if (k.seg != nullptr && k.seg[cell] != 0u) empty = false;
         if (k.pred != nullptr && k.pred[cell] != 0u) empty = false;
@@ -1185,6 +1197,7 @@ extern "C" int mrirt_render_brats_ex(const MrirtBratsParams* p, const MrirtRende
     a.stats = stats_dev;
     if (a.map.numBlocks == 0) return MRIRT_OK;   // a rank that owns no tile
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (g_family_probe != nullptr && (cfg.slab || cfg.ring)) { *g_family_probe = cfg.slab ? MRIRT_KERNEL_SLAB : MRIRT_KERNEL_RING; return MRIRT_OK; }
     if (cfg.slab) return launch_slab_march(a, cfg.math == MRIRT_MATH_STRICT, cfg.shade, s);
     if (cfg.ring) return launch_ring_march(a, cfg.math == MRIRT_MATH_STRICT, cfg.shade, s);
     return cfg.math == MRIRT_MATH_STRICT ? launch_layout<true>(a, cfg.layout, cfg.shade, cfg.pipe, s)
@@ -1238,6 +1251,8 @@ extern "C" int mrirt_render_brats_skip(const MrirtBratsParams* p, const MrirtRen
         a.skipDist = reinterpret_cast<uint8_t*>(skip->mask + skip_bit_words(cells));
         a.mX = mx; a.mXY = mx * my; a.mY = my; a.mZ = mz;
         a.leap = (a.debugFlags & 2u) == 0u ? 1u : 0u;
+    } else if (ok && g_family_probe != nullptr) {
+        a.skipDist = reinterpret_cast<uint8_t*>(skip->mask);          // (probe: the launchers only test it against NULL)
     } else if (ok) {
         SkipArgs k;
         const uint32_t mx = (p->dims[0] + 7) / 8, my = (p->dims[1] + 7) / 8, mz = (p->dims[2] + 7) / 8;
@@ -1276,6 +1291,18 @@ extern "C" int mrirt_brats_skip_applicable(const MrirtBratsParams* p, const Mrir
     const int rc = prepare(p, ext, vol, labels, preds, true, p ? (int64_t)p->imageSize[0] : 0, a, cfg);
     if (rc != MRIRT_OK) return rc;
     return skip_applicable(p, a, cfg, skip) ? 1 : 0;
+}
+
+// Which kernel family the render call with these arguments launches (host-only, nothing is launched): MrirtKernelFamily,
+// possibly with MRIRT_KERNEL_SKIPPING / MRIRT_KERNEL_LABEL_CELLS or'ed in; < 0: the status the render call would return.
+extern "C" int mrirt_brats_kernel_family(const MrirtBratsParams* p, const MrirtRenderExt* ext, const void* const vol[4],
+                                         const void* labels, const void* preds, const MrirtSkip* skip) {
+    int family = MRIRT_KERNEL_NONE;
+    g_family_probe = &family;
+    const int64_t pitch = p ? (int64_t)p->imageSize[0] : 0;
+    const int rc = mrirt_render_brats_skip(p, ext, vol, labels, preds, skip, reinterpret_cast<void*>(uintptr_t(16)), pitch, nullptr, nullptr);
+    g_family_probe = nullptr;
+    return rc != MRIRT_OK ? rc : family;
 }
 
 extern "C" int mrirt_render_brats(const MrirtBratsParams* params, const float* const vol[4],

@@ -122,6 +122,19 @@ template <> struct M<true> {
         const float e = __builtin_fmaf(-q, u.d, x);
         return __builtin_fmaf(e, u.r, q);
     }
+    // The same for numerators that come from VOXEL DATA (the weighted intensity, the window test, the z-score): a volume may
+    // hold +-inf or NaN, and Markstein's residual is then inf - inf = NaN where the IEEE quotient is +-inf — saturate() would
+    // turn that into 0 instead of 1.  q = x r already IS the IEEE quotient whenever it is not finite (inf
+    // for an infinite x with the quotient's sign, NaN for a NaN), so it is returned as is: one compare and one select.
+    // (Domain note: a FINITE x whose product with r overflows where x / d itself would round to the largest float is not
+    // distinguished — |x / d| >= 2^127, forty orders of magnitude beyond anything a window test can tell apart.)
+    static __device__ __forceinline__ float divu_data(float x, const UDiv& u) {
+        if (!u.exact) return x / u.d;
+        const float q = x * u.r;
+        const float e = __builtin_fmaf(-q, u.d, x);
+        const float res = __builtin_fmaf(e, u.r, q);
+        return __builtin_fabsf(q) < INFINITY ? res : q;
+    }
     static __device__ __forceinline__ float pow(float x, float y) {
         return y == 1.0f ? x : (float)::pow((double)x, (double)y);   // pow(x,1) == x exactly
     }
@@ -131,6 +144,7 @@ template <> struct M<true> {
 
 template <> struct M<false> {
     static __device__ __forceinline__ float divu(float x, const UDiv& u) { return x * u.r; }
+    static __device__ __forceinline__ float divu_data(float x, const UDiv& u) { return x * u.r; }
     static __device__ __forceinline__ float lerp(float a, float b, float t) { return __builtin_fmaf(t, b - a, a); }
     static __device__ __forceinline__ float exp(float x, const ExpConsts&) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
     static __device__ __forceinline__ float exp_lit(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }

@@ -21,6 +21,10 @@ from .params import brats_params, render_ext, sdf_params, volume_params
 ArrayLike = Union[np.ndarray, torch.Tensor]
 
 
+TRACE_HOOK = None      # diagnostics: a callable(str) that receives the device addresses and sizes of every render_brats call's
+                       # tensors (tests/conftest.py sets it for fault-attribution runs); None in normal use
+
+
 def _require_gpu() -> torch.device:
     if not torch.cuda.is_available():
         raise RuntimeError("mrirt: no HIP device visible — the ray-marcher has no CPU fallback "
@@ -268,6 +272,32 @@ def _bind_brats(params, intensities, labels, preds, ext, dev, pred_stream: bool 
     return P, E, vols, lab, prd
 
 
+KERNEL_FAMILIES = {0: "none", 1: "generic", 2: "pipelined", 3: "rolling", 4: "slab", 5: "ring"}
+
+
+def kernel_family(params: Mapping[str, Any], ext: Optional[Mapping[str, Any]] = None, skip: bool = False) -> Dict[str, Any]:
+    """Which march kernel the library takes for a K1 launch with these parameters (``mrirt_brats_kernel_family``: a host-only
+    query, no GPU needed, nothing is launched; the grids are stood in for by placeholder addresses — only ``gParams`` and
+    ``ext`` decide).  ``{"family": "generic" | "pipelined" | "rolling" | "slab" | "ring" | "none", "skipping": bool,
+    "label_cells": bool}``.  The generic kernel is the fall-back with 64-bit offsets: VG / QUAD grids >= 4 GiB, label grids
+    >= 2^30 elements, LINEAR grids >= 2^30 voxels, BRICK grids, shaded LINEAR."""
+    P = brats_params(params)
+    E = render_ext(dict(ext or {}))
+    fake = C.c_void_p(0x1000)
+    vp = (C.c_void_p * 4)(*[fake if P.volEnabled[m] != 0 else None for m in range(4)])
+    S = None
+    if skip:
+        S = _lib.Skip()
+        for m in range(4):
+            S.macroUb[m] = 0x1000 if P.volEnabled[m] != 0 else None
+        S.macroSeg = S.macroPred = S.mask = 0x1000
+        S.maskWords = 0xFFFFFFFF
+    rc = int(_lib.lib().mrirt_brats_kernel_family(C.byref(P), C.byref(E), vp, fake, fake, C.byref(S) if S is not None else None))
+    if rc < 0:
+        _lib.check(rc, "mrirt_brats_kernel_family")
+    return {"family": KERNEL_FAMILIES[rc & 15], "skipping": bool(rc & _lib.KERNEL_SKIPPING), "label_cells": bool(rc & _lib.KERNEL_LABEL_CELLS)}
+
+
 _last_skip_mask: Optional[torch.Tensor] = None
 skip_map_builds = 0              # how many launches built a map (tests: a repeated frame must not)
 SKIP_MIN_EMPTY_FRACTION = 0.10   # of the 8^3 macro cells; below it skip=True renders with the plain kernels (same bits)
@@ -391,6 +421,10 @@ def render_brats(params: Mapping[str, Any], intensities: Sequence[Optional[Union
         o, pitch = _alloc_out(int(P.imageSize[0]), int(P.imageSize[1]), E, dev, out)
         vp = (C.c_void_p * 4)(*[C.c_void_p(t.data_ptr()) if t is not None else None for t in vols])
         st = torch.zeros(2, dtype=torch.int64, device=dev) if stats else None
+        if TRACE_HOOK is not None:
+            TRACE_HOOK(("[render_brats] " + " ".join(f"{k}={t.data_ptr():#x}+{t.numel() * t.element_size():#x}" for k, t in
+                         [(f"vol{m}", v) for m, v in enumerate(vols) if v is not None] + [("lab", lab), ("prd", prd), ("out", o), ("st", st)]
+                         if t is not None) + f" skip={skip}\n"))
         S = entry = hold = None
         if skip:
             S, entry, hold = _bind_skip(P, E, vp, lab, prd, intensities, labels, preds, dev, stream)

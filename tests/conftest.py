@@ -65,3 +65,64 @@ def _fresh_hip_library():
     except Exception as e:
         print(f"[conftest] abort trace not installed: {e}")
     yield
+
+
+# ---- fault attribution (opt-in: MRIRT_TRACE_CALLS=1) ---------------------------------------------------------
+# With AMD_SERIALIZE_KERNEL=3 the runtime waits for every kernel, so a GPU fault surfaces inside the call that launched the
+# faulting kernel.  This writes, to the (captured) stderr whose tail the abort trace prints: per test the caching allocator's
+# segments, and per C-ABI call its name and integer / pointer arguments — enough to name the kernel and to place the fault
+# address relative to the buffers it was given.
+_TRACE_FH = None
+
+
+def _trace_write(text: str) -> None:
+    """To the captured stderr (whose tail the abort trace prints) and, when MRIRT_TRACE_FILE names one, to a file that
+    survives a passing run too."""
+    global _TRACE_FH
+    os.write(2, text.encode())
+    path = os.environ.get("MRIRT_TRACE_FILE")
+    if path:
+        if _TRACE_FH is None:
+            os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+            _TRACE_FH = open(path, "a", buffering=1)
+        _TRACE_FH.write(text)
+
+
+class _TracedLib:
+    def __init__(self, handle):
+        object.__setattr__(self, "_h", handle)
+
+    def __getattr__(self, name):
+        fn = getattr(self._h, name)
+        if not callable(fn) or not name.startswith("mrirt_"):
+            return fn
+
+        def call(*args):
+            def show(a):
+                v = getattr(a, "value", a)
+                return hex(v) if isinstance(v, int) and v > 0xFFFF else str(v) if isinstance(v, (int, float, type(None))) else type(a).__name__
+            _trace_write(f"[call] {name}(" + ", ".join(show(a) for a in args) + ")\n")
+            return fn(*args)
+        return call
+
+    def __setattr__(self, name, value):
+        setattr(self._h, name, value)
+
+
+@pytest.fixture(autouse=True)
+def _trace_calls(request):
+    if not os.environ.get("MRIRT_TRACE_CALLS"):
+        yield
+        return
+    import torch
+    import mrirt
+    real = mrirt._lib.lib()
+    if not isinstance(mrirt._lib._LIB, _TracedLib):
+        mrirt._lib._LIB = _TracedLib(real)
+    mrirt.render.TRACE_HOOK = _trace_write
+    lines = [f"[test] {request.node.nodeid}"]
+    if torch.cuda.is_available():
+        segs = sorted((s["address"], s["total_size"], sum(b["size"] for b in s["blocks"] if b["state"] != "inactive")) for s in torch.cuda.memory_snapshot())
+        lines += [f"[seg] {a:#x}..{a + n:#x} ({n >> 20} MiB, {u >> 10} KiB in use)" for a, n, u in segs]
+    _trace_write("\n".join(lines) + "\n")
+    yield

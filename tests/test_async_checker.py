@@ -70,3 +70,35 @@ def test_the_tool_directory_comes_from_the_environment(monkeypatch, tmp_path):
         (tmp_path / t).write_text("")
     monkeypatch.setenv("MRIRT_LLVM_BIN", str(tmp_path))
     assert chk.llvm_bin() == tmp_path
+
+
+# ---- the VALU-writes-SGPR -> vector-memory-reads-it hazard (5 wait states on gfx9, not interlocked) ----------------------------
+def test_a_base_pointer_restored_by_readlane_right_before_a_gather_is_reported():
+    """The root cause of the memory-access fault of rounds 3 / 4, as it stood in brats_march_pipe_kernel<strict, QUAD, 3, labels>."""
+    rows = [("v_readlane_b32 s60, v110, 6", 8), ("v_trunc_f32_e32 v48, v46", 4), ("v_med3_f32 v64, v64, s24, 0", 8),
+            ("v_readlane_b32 s61, v110, 7", 8), ("v_sub_f32_e32 v49, v46, v48", 4), ("v_trunc_f32_e32 v90, v64", 4),
+            ("global_load_dwordx4 v[26:29], v42, s[60:61]", 8), ("s_waitcnt vmcnt(0)", 4), ("s_endpgm", 4)]
+    found = chk.hazard_scan("k", listing(rows))
+    assert len(found) == 1 and found[0][2] == "v_readlane_b32 s61, v110, 7" and found[0][3] == 2
+
+
+def test_five_wait_states_or_a_scalar_copy_clear_the_hazard():
+    padded = [("v_readlane_b32 s61, v110, 7", 8), ("s_nop 4", 4), ("global_load_dwordx4 v[26:29], v42, s[60:61]", 8), ("s_endpgm", 4)]
+    assert chk.hazard_scan("k", listing(padded)) == []
+    short = [("v_readlane_b32 s61, v110, 7", 8), ("s_nop 2", 4), ("global_load_dwordx4 v[26:29], v42, s[60:61]", 8), ("s_endpgm", 4)]
+    assert len(chk.hazard_scan("k", listing(short))) == 1
+    # what the asm gathers do now: the vector-memory instruction reads an SGPR pair a SCALAR move wrote
+    copied = [("v_readlane_b32 s61, v110, 7", 8), ("s_mov_b64 s[30:31], s[60:61]", 4), ("global_load_dwordx4 v[26:29], v42, s[30:31]", 8), ("s_endpgm", 4)]
+    assert chk.hazard_scan("k", listing(copied)) == []
+
+
+def test_the_hazard_is_found_across_a_branch_and_for_compare_and_carry_writers():
+    # the writer sits in a predecessor block that jumps to the load
+    rows = [("v_cmp_gt_f32_e64 s[8:9], v1, v2", 8), ("s_branch 1", 4), ("s_nop 7", 4),
+            ("buffer_load_dword v3, v4, s[8:11], 0 offen", 8), ("s_endpgm", 4)]
+    found = chk.hazard_scan("k", listing(rows))
+    assert len(found) == 1 and found[0][2].startswith("v_cmp_gt_f32_e64")
+    carry = [("v_div_scale_f32 v7, s[34:35], s30, s30, v6", 8), ("global_load_dwordx4 v[8:11], v5, s[34:35]", 8), ("s_endpgm", 4)]
+    assert len(chk.hazard_scan("k", listing(carry))) == 1
+    vcc = [("v_cmp_eq_u32_e32 vcc, 1, v7", 4), ("global_load_dword v1, v2, vcc", 8), ("s_endpgm", 4)]
+    assert len(chk.hazard_scan("k", listing(vcc))) == 1

@@ -351,10 +351,12 @@ def test_full_size_properties(env):
     from mrirt import tiles
     parts = [mrirt.render_brats(p, [gb], ext=tiles.shard_ext(ext, r, 4, 64)) for r in range(4)]
     assert torch.equal(tiles.assemble_frame(torch.stack(parts), image, image, 64, 4), b)
-    # oracle on a 16-row band through the middle of the image (seconds of CPU time)
-    rows = (504, 520)
-    ref, aux = oc.brats_main(p, [vol], None, None, synth.SHADE_EXT, return_aux=True, rows=rows)
-    assert np.abs(img[rows[0]:rows[1]] - ref).max() <= STRICT_TOL
+    # the oracle over the WHOLE frame — all 1024 rows (the C/OpenMP oracle renders config 3 in a couple of
+    # seconds on the GPU box's host): image bits and the live-sample count
+    ref, aux = oc.brats_main(p, [vol], None, None, synth.SHADE_EXT, return_aux=True)
+    assert ref.shape == img.shape
+    assert np.abs(img - ref).max() <= STRICT_TOL and np.array_equal(img, ref)
+    assert aux["live_samples"] == sa["live_samples"]
     # ERT really fires in this configuration, and linearity in bgColor holds:
     # C(bg) = C(0) + bg exactly where no sample contributes; elsewhere C >= bg
     p2 = dict(p, bgColor=np.array([0.25, 0.25, 0.25], np.float32))
@@ -454,6 +456,13 @@ def test_c4_full_size_tiles_over_eight_ranks(env, layout):
     assert torch.equal(mrirt.detile(gathered, image, image, tile, world), whole)
     assert live == sw["live_samples"] and shaded == sw["shaded_samples"]
     assert 0 < live < image * image * steps
+    # ... and the frame itself against the oracle: 128 rows through the long centre rays and 32 at the top edge of the
+    # 2048^2 image (C4 used to be compared only with itself)
+    oc = env["oc"]
+    img = whole.cpu().numpy()
+    for rows in ((960, 1088), (0, 32)):
+        ref = oc.brats_main(p, [vol], None, None, synth.SHADE_EXT, rows=rows)
+        assert np.array_equal(img[rows[0]:rows[1]], ref), rows
 
 
 def test_c2_full_size_against_the_oracle(env):

@@ -285,3 +285,43 @@ def test_inline_asm_gathers_are_not_touched_before_their_wait():
     r = subprocess.run([sys.executable, str(root / "tools" / "check_async_loads.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-500:]
     assert "0 kernels failing" in r.stdout
+
+
+def test_kernel_family_choices_incl_the_4gib_fallbacks():
+    """mrirt_brats_kernel_family (host-only): the launches of the BASELINE configs take the kernels DESIGN.md names, and the
+    configurations real volumes can reach beyond 32-bit offsets drop to the generic kernel: VG / QUAD grids
+    >= 4 GiB (a 645^3 channel; 1024 x 1024 x 272), label grids >= 2^30 elements with an overlay shown, LINEAR grids >= 2^30
+    voxels.  Skipping never applies to those."""
+    from mrirt import render, synth
+    fam = render.kernel_family
+    c3 = synth.brats_scene(512, 1024, 512, channels=1, intensity_alpha=16.0)
+    assert fam(c3, dict(synth.SHADE_EXT, layout="vga")) == {"family": "pipelined", "skipping": False, "label_cells": False}
+    assert fam(c3, dict(synth.SHADE_EXT, layout="vga"), skip=True)["skipping"]
+    assert fam(c3, dict(synth.SHADE_EXT, layout="vga", kernelVariant=64))["family"] == "slab"
+    assert fam(c3, dict(synth.SHADE_EXT, layout="vga", kernelVariant=2048))["family"] == "ring"
+    assert fam(c3, dict(synth.SHADE_EXT, layout="brick"))["family"] == "generic"
+    c2 = synth.brats_scene(256, 512, 256, channels=4, show_seg=True, intensity_alpha=0.4)
+    assert fam(c2, dict(layout="quad", labelLayout="labcell")) == {"family": "pipelined", "skipping": False, "label_cells": True}
+    assert fam(c2, dict(layout="quad", labelLayout="brick"), skip=True) == {"family": "pipelined", "skipping": True, "label_cells": False}
+    assert fam(c2, dict(layout="linear"))["family"] == "pipelined"                 # the plain ABI's own buffers
+    four = synth.brats_scene(256, 512, 256, channels=4)
+    assert fam(four, dict(synth.SHADE_EXT, layout="vga"))["family"] == "rolling"
+    assert fam(dict(four, showSeg=1), dict(synth.SHADE_EXT, layout="vga"))["family"] == "generic"      # overlays: the generic kernel measured faster
+    # ---- beyond 32-bit byte offsets ----
+    wide = synth.brats_scene(0, 256, 200, dims=(1024, 1024, 272), channels=1)
+    assert fam(wide, dict(synth.SHADE_EXT, layout="vg")) == {"family": "generic", "skipping": False, "label_cells": False}
+    assert fam(wide, dict(synth.SHADE_EXT, layout="vg"), skip=True) == {"family": "generic", "skipping": False, "label_cells": False}
+    assert fam(synth.brats_scene(645, 256, 200, channels=1), dict(layout="quad"))["family"] == "generic"
+    assert fam(synth.brats_scene(644, 256, 200, channels=1), dict(layout="quad"))["family"] == "pipelined"     # 3.98 GiB: still 32-bit
+    big = synth.brats_scene(1024, 128, 200, channels=1, show_seg=True)
+    assert fam(big, dict(layout="linear"))["family"] == "generic"                  # 2^30 voxels, 2^30 label words
+    assert fam(synth.brats_scene(0, 128, 200, dims=(1024, 1024, 1020), channels=1, show_seg=True), dict(layout="quad", labelLayout="brick"))["family"] == "generic"
+    # VGA copies past 2^28 elements are refused outright (32-bit byte offsets inside a copy): an error, not a fault
+    import pytest as _pt
+    with _pt.raises(_lib_error()):
+        fam(synth.brats_scene(0, 64, 64, dims=(1024, 1024, 272), channels=1), dict(synth.SHADE_EXT, layout="vga"))
+
+
+def _lib_error():
+    from mrirt import _lib
+    return _lib.MrirtError

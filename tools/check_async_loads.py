@@ -141,6 +141,92 @@ def check(name, lines):
     return bad
 
 
+# ---- the gfx9 hazard "a VALU instruction writes an SGPR, a vector-memory instruction reads it fewer than 5 wait states later" ----
+# The hardware does not interlock it; the compiler pads loads IT issues with s_nop, but not inline asm (LLVM's hazard recogniser
+# does not look inside asm statements).  The asm gathers therefore copy their base pointer with an s_mov_b64 inside the
+# statement (csrc/brats_device.h); this scan proves, on every kernel of the built library, that no vector-memory
+# instruction is left reading a VALU-written SGPR too early — e.g. a spilled base pointer restored with v_readlane_b32 in
+# front of a gather, which is what faulted once in round 3 and once in round 4.
+SREG = re.compile(r"\bs\[(\d+):(\d+)\]|\bs(\d+)\b")
+VMEM = re.compile(r"^(global_|buffer_|flat_|scratch_)\w+\s+(.*)$")
+HAZARD_WAIT_STATES = 5
+
+
+def sregs(tok):
+    out = set()
+    for m in SREG.finditer(tok):
+        if m.group(1) is not None:
+            out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+        else:
+            out.add(int(m.group(3)))
+    if "vcc" in tok:
+        out.update((106, 107))
+    return out
+
+
+def valu_sgpr_writes(text):
+    """SGPRs a VALU instruction writes: the destination of v_readlane / v_readfirstlane / VOP3 compares, the carry-out of
+    v_div_scale / v_add_co & co, VCC for the e32 compares."""
+    mn = text.split()[0]
+    if not mn.startswith("v_"):
+        return set()
+    ops = text.split(None, 1)[1].split(",") if " " in text else []
+    w = sregs(ops[0]) if ops else set()
+    if mn.startswith(("v_div_scale", "v_add_co", "v_sub_co", "v_subrev_co", "v_addc_co", "v_subb_co", "v_subbrev_co", "v_mad_u64", "v_mad_i64")) and len(ops) > 1:
+        w |= sregs(ops[1])
+    if mn.startswith("v_cmp") and ops and not re.match(r"^\s*(s\[|s\d|vcc)", ops[0]):
+        w = {106, 107}
+    return w
+
+
+def hazard_scan(name, lines):
+    """[(line_no, vmem instruction, writer instruction, wait states)] for every vector-memory instruction that reads an SGPR a
+    VALU instruction wrote fewer than HAZARD_WAIT_STATES wait states earlier, on ANY path through the function."""
+    ins = parse(lines)
+    if not ins:
+        return []
+    index = {addr: i for i, (_, addr, _, _) in enumerate(ins)}
+    preds = {i: [] for i in range(len(ins))}
+    for i, (_, addr, size, text) in enumerate(ins):
+        m = BRANCH.match(text)
+        falls = not (text.startswith("s_endpgm") or (m and m.group(1) == "s_branch"))
+        if falls and i + 1 < len(ins):
+            preds[i + 1].append(i)
+        if m:
+            off = int(m.group(2))
+            off = off - 65536 if off >= 32768 else off
+            tgt = index.get(addr + size + 4 * off)
+            if tgt is not None:
+                preds[tgt].append(i)
+    found = []
+    for i, (no, _, _, text) in enumerate(ins):
+        m = VMEM.match(text)
+        if not m:
+            continue
+        need = sregs(m.group(2))
+        if not need:
+            continue
+        # walk backwards over every path until HAZARD_WAIT_STATES wait states have been seen
+        stack, seen, hit = [(p, 0) for p in preds[i]], set(), None
+        while stack and hit is None:
+            j, ws = stack.pop()
+            if (j, ws) in seen or ws >= HAZARD_WAIT_STATES:
+                continue
+            seen.add((j, ws))
+            t = ins[j][3]
+            if valu_sgpr_writes(t) & need:
+                hit = (no, text, t, ws)
+                break
+            if t.startswith("s_waitcnt") or t.startswith("s_barrier"):
+                pass                                      # (wait states still only count issue slots)
+            step = int(t.split()[1]) + 1 if t.startswith("s_nop") else 1
+            for p in preds[j]:
+                stack.append((p, ws + step))
+        if hit:
+            found.append(hit)
+    return found
+
+
 TOOLS = ("llvm-objcopy", "clang-offload-bundler", "llvm-objdump")
 MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
 
@@ -229,7 +315,20 @@ def main():
             for no, ins in bad[:6]:
                 print(f"   line {no}: {ins}")
     print(f"check_async_loads: {checked} kernels, {loads} gathers checked, {failures} kernels failing")
-    return 1 if failures or not checked or not loads else 0
+    hz_kernels = hz = vm = 0
+    for name, lines in funcs.items():
+        if name.startswith("__"):
+            continue
+        vm += sum(1 for _, t in lines if VMEM.match(t.split("//")[0].strip()))
+        bad = hazard_scan(name, lines)
+        if bad:
+            hz_kernels += 1
+            hz += len(bad)
+            print(f"HAZARD {name}: {len(bad)} vector-memory instruction(s) read an SGPR a VALU instruction wrote < {HAZARD_WAIT_STATES} wait states earlier")
+            for no, ins, writer, ws in bad[:6]:
+                print(f"   line {no}: {writer}   ->   {ins}   ({ws} wait state(s) between)")
+    print(f"check_async_loads: VALU-writes-SGPR -> VMEM hazard: {len(funcs)} kernels, {vm} vector-memory instructions, {hz} violation(s) in {hz_kernels} kernel(s)")
+    return 1 if failures or hz or not checked or not loads else 0
 
 
 if __name__ == "__main__":

@@ -88,6 +88,10 @@ def main():
             # line look-ups per clock per CU (NOT a roof by itself: the micro-benchmark reaches 0.93-0.99 with one line per quad or
             # with bank conflicts, 1.67-1.76 with conflict-free multi-line quads)
             on_chip["l1_tag_accesses_per_clk_per_cu"] = round(mean["TCP_TOTAL_CACHE_ACCESSES_sum"] / cyc / CUS, 4)
+        if "TCP_TOTAL_CACHE_ACCESSES_sum" in mean and "TCP_TCC_READ_REQ_sum" in mean:
+            # vector-L1 hit rate: line look-ups that did not go on to L2 (read requests to the TCC per look-up)
+            entry["tcp_tcc_read_requests"] = round(mean["TCP_TCC_READ_REQ_sum"])
+            on_chip["l1_hit_rate"] = round(1.0 - mean["TCP_TCC_READ_REQ_sum"] / mean["TCP_TOTAL_CACHE_ACCESSES_sum"], 4)
         if "SQ_INSTS_VALU" in mean:
             entry["valu_instructions"] = round(mean["SQ_INSTS_VALU"])
             # a SIMD-32 retires one wave64 VALU instruction per 2 clocks at best (guide: v_fma_f32 2 cyc; fp64 and

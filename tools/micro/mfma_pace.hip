@@ -83,6 +83,36 @@ __global__ __launch_bounds__(256, 1) void k(const uint4* __restrict__ w, unsigne
     sink[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// sin(2 pi x), x in revolutions (what v_sin_f32 takes), as a range-reduced odd minimax polynomial: r = x - rint(x) in
+// [-0.5, 0.5], s = r P(r^2), P of degree 3 (odd degree 7): max error 2.5e-4 < 2^-10, below the bf16 rounding that follows
+// (VERDICT r3 #3 asked whether this beats v_sin_f32's 8 issue cycles beside the MFMAs).  7 plain VALU instructions per value.
+__device__ __forceinline__ float sin_poly(float x) {
+    const float r = x - __builtin_rintf(x), r2 = r * r;
+    float p = __builtin_fmaf(-56.086395f, r2, 77.93035f);
+    p = __builtin_fmaf(p, r2, -41.09373f);
+    p = __builtin_fmaf(p, r2, 6.2786355f);
+    return r * p;
+}
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 sin_poly2(f32x2 x) {       // the same on a register pair: v_pk_add / v_pk_mul / v_pk_fma_f32
+    const f32x2 n = { __builtin_rintf(x.x), __builtin_rintf(x.y) };
+    const f32x2 r = x - n, r2 = r * r;
+    f32x2 p = __builtin_elementwise_fma((f32x2){ -56.086395f, -56.086395f }, r2, (f32x2){ 77.93035f, 77.93035f });
+    p = __builtin_elementwise_fma(p, r2, (f32x2){ -41.09373f, -41.09373f });
+    p = __builtin_elementwise_fma(p, r2, (f32x2){ 6.2786355f, 6.2786355f });
+    return r * p;
+}
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ h2 sin_poly_h2(f32x2 x) {        // range reduction in fp32, polynomial in packed f16 (v_pk_fma_f16: one pass)
+    const f32x2 n = { __builtin_rintf(x.x), __builtin_rintf(x.y) };
+    const f32x2 rf = x - n;
+    const h2 r = { (_Float16)rf.x, (_Float16)rf.y }, r2 = r * r;
+    h2 p = __builtin_elementwise_fma((h2){ (_Float16)-56.086395f, (_Float16)-56.086395f }, r2, (h2){ (_Float16)77.93035f, (_Float16)77.93035f });
+    p = __builtin_elementwise_fma(p, r2, (h2){ (_Float16)-41.09373f, (_Float16)-41.09373f });
+    p = __builtin_elementwise_fma(p, r2, (h2){ (_Float16)6.2786355f, (_Float16)6.2786355f });
+    return r * p;
+}
+
 // The weight-stationary kernel's pass structure: 16 MFMAs into acc while the PREVIOUS pass's accumulator is activated
 // (2 v_sin per step in steps 2..9, packed converts), one B fragment per step from LDS.  VARIANT 0: accumulators in
 // VGPRs (VALU reads them directly); 1: no activation at all; 2: activation on registers MFMAs never wrote;
@@ -125,7 +155,40 @@ __global__ __launch_bounds__(256, 1) void kpass(const uint4* __restrict__ w, uns
                         keep += __builtin_bit_cast(float, pk);
                     }
                 }
-                if (VARIANT != 1 && VARIANT != 4 && ks >= 2 && ks <= 9) {
+                if (VARIANT == 5) {                       // as 4, the sine as 7 plain VALU instructions (sin_poly)
+                    f32x16& src = acc[p ^ 1];
+                    if (ks == 0) asm volatile("s_nop 15" : "+v"(src));
+                    if ((ks & 3) == 0) bq = __builtin_bit_cast(f32x4, base[(ks >> 2) * 64 + 8]);
+                    const float bb = (ks & 3) == 0 ? bq.x : ((ks & 3) == 1 ? bq.y : ((ks & 3) == 2 ? bq.z : bq.w));
+                    src[ks] = sin_poly(src[ks] + bb);
+                    if (ks & 1) {
+                        typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+                        bf2 pk = { (__bf16)src[ks - 1], (__bf16)src[ks] };
+                        keep += __builtin_bit_cast(float, pk);
+                    }
+                }
+                if (VARIANT == 6 || VARIANT == 7) {       // two values every second step: packed f32 (6) / packed f16 (7) polynomial
+                    f32x16& src = acc[p ^ 1];
+                    if (ks == 0) asm volatile("s_nop 15" : "+v"(src));
+                    if ((ks & 3) == 0) bq = __builtin_bit_cast(f32x4, base[(ks >> 2) * 64 + 8]);
+                    if (ks & 1) {
+                        const f32x2 bb = (ks & 2) ? (f32x2){ bq.z, bq.w } : (f32x2){ bq.x, bq.y };
+                        const f32x2 xin = (f32x2){ src[ks - 1], src[ks] } + bb;
+                        typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+                        if (VARIANT == 6) {
+                            const f32x2 y = sin_poly2(xin);
+                            src[ks - 1] = y.x; src[ks] = y.y;
+                            bf2 pk = { (__bf16)y.x, (__bf16)y.y };
+                            keep += __builtin_bit_cast(float, pk);
+                        } else {
+                            const h2 y = sin_poly_h2(xin);
+                            src[ks - 1] = (float)y.x;
+                            bf2 pk = { (__bf16)(float)y.x, (__bf16)(float)y.y };
+                            keep += __builtin_bit_cast(float, pk);
+                        }
+                    }
+                }
+                if (VARIANT != 1 && VARIANT < 4 && ks >= 2 && ks <= 9) {
                     f32x16& src = VARIANT == 2 ? other : acc[p ^ 1];
                     if (ks == 2) asm volatile("s_nop 15" : "+v"(src));
                     const float a0 = __builtin_amdgcn_sinf(src[2 * ks - 4]), a1 = __builtin_amdgcn_sinf(src[2 * ks - 3]);
@@ -185,6 +248,9 @@ int main() {
     runpass<2>("pass: activation of registers MFMA never wrote", w, out, sink);
     runpass<3>("pass: accumulators in AGPRs (accvgpr_read)", w, out, sink);
     runpass<4>("pass: 1 value/step x 16, bias add + sin + cvt", w, out, sink);
+    runpass<5>("pass: 1 value/step, sine = 7-VALU polynomial", w, out, sink);
+    runpass<6>("pass: 2 values/2 steps, polynomial in v_pk_*_f32", w, out, sink);
+    runpass<7>("pass: 2 values/2 steps, polynomial in v_pk_*_f16", w, out, sink);
     run<6>("builtin + ds_read_b128 per step", w, out, sink);
     return 0;
 }
