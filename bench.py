@@ -74,6 +74,7 @@ def parse():
     ap.add_argument("--alpha", type=float, default=16.0, help="intensityAlpha (16 = dense preset: ERT fires)")
     ap.add_argument("--variant", type=int, default=0, help="kernelVariant (experiments)")
     ap.add_argument("--tile", type=int, default=64)
+    ap.add_argument("--tile-skew", type=int, default=-1, help="tileSkew of the N>1 deal; -1 = tiles.balanced_skew (diagonals), 0 = plain row-major deal")
     ap.add_argument("--cpu-rows", type=int, default=-1, help="rows of the frame the CPU baseline renders; 0 = skip, -1 = auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-inr", action="store_true", help="skip the INR (MFMA) side measurement")
@@ -130,7 +131,8 @@ def dry_run(a, world, rank):
         px = torch.arange(a.tile * a.tile * 4, dtype=torch.float32).reshape(a.tile, a.tile, 4)
         return px / 16.0 + float(t)
 
-    ex = tiles.FrameExchange(image, image, a.tile, torch.float32, "cpu", depth=2, dst=0)
+    skew = tiles.balanced_skew(image, a.tile, world)
+    ex = tiles.FrameExchange(image, image, a.tile, torch.float32, "cpu", depth=2, dst=0, skew=skew)
     owned = list(range(rank, n_tiles, world))
     assert len(owned) == ex.n_local
     t0 = time.perf_counter()
@@ -152,7 +154,7 @@ def dry_run(a, world, rank):
     if rank == 0:
         ok = frame is not None and tuple(frame.shape) == (image, image, 4)
         for t in range(n_tiles if ok else 0):
-            x0, y0 = tiles.tile_origin(t, image, a.tile)
+            x0, y0 = tiles.tile_origin(t, image, a.tile, skew)
             want = tile_pattern(t)[: image - y0, : image - x0]
             ok = ok and torch.equal(frame[y0:y0 + a.tile, x0:x0 + a.tile], want)
         print(json.dumps({"metric": "dry run of the N-rank launcher and exchange (no GPU, no rendering)", "value": 0.0,
@@ -376,7 +378,7 @@ def parity_block(gpu_frame, gpu_live, oracle_band, n_image):
             "live_samples_oracle": int(oracle_band["live"]) if whole else None}
 
 
-def scaling_model(dev, grid, n, march_steps, ext, tile, alpha, reps=10):
+def scaling_model(dev, grid, n, march_steps, ext, tile, alpha, reps=10, skew_auto=True):
     """What ONE GPU can say about 1 -> 8 scaling, clearly an emulation: BASELINE config 4
     (2048^2 px of the same volume) cut into `tile`^2 tiles dealt round-robin; for N = 1, 2, 4, 8 EVERY rank's share is
     rendered on this GPU (HIP events, `reps` launches each) and the slowest rank is what an N-GPU frame would wait for.
@@ -389,11 +391,12 @@ def scaling_model(dev, grid, n, march_steps, ext, tile, alpha, reps=10):
     from mrirt import synth, tiles
     image = 2048
     p = synth.brats_scene(n, image, march_steps, channels=1, intensity_alpha=alpha)
-    share, worst_rank, live_max = {}, {}, {}
+    share, worst_rank, mean_share, skews = {}, {}, {}, {}
     for world in (1, 2, 4, 8):
         times = []
+        skews[world] = tiles.balanced_skew(image, tile, world) if skew_auto else 0
         for r in range(world):
-            e = tiles.shard_ext(ext, r, world, tile)
+            e = tiles.shard_ext(ext, r, world, tile, skews[world])
             out = mrirt.render_brats(p, [grid], ext=e)
             mrirt.render_brats(p, [grid], out=out, ext=e)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -405,6 +408,7 @@ def scaling_model(dev, grid, n, march_steps, ext, tile, alpha, reps=10):
             times.append(e0.elapsed_time(e1) / reps)
             del out
         share[world] = max(times)
+        mean_share[world] = float(np.mean(times))
         worst_rank[world] = int(np.argmax(times))
     # the root's part of the exchange: local copy of its own tiles + the de-tiling kernel over the gathered buffer
     world = 8
@@ -424,9 +428,11 @@ def scaling_model(dev, grid, n, march_steps, ext, tile, alpha, reps=10):
     wire = {w: (0.0 if w == 1 else tiles.local_tile_count(image, image, tile, 0, w) * tile * tile * 16 / (link_gbs * eff * 1e9) * 1e3)
             for w in (1, 2, 4, 8)}
     return {"emulated_on_one_gpu": True,
-            "workload": f"C4: {n}^3 volume, {image}x{image} px, {march_steps} steps/ray, {tile}x{tile} tiles round-robin; every rank's share "
-                        "rendered on this one GPU, slowest rank per world size",
+            "workload": f"C4: {n}^3 volume, {image}x{image} px, {march_steps} steps/ray, {tile}x{tile} tiles dealt along diagonals (tileSkew); "
+                        "every rank's share rendered on this one GPU, slowest rank per world size",
+            "tile_skew": {str(w): skews[w] for w in skews},
             "share_ms": {str(w): round(share[w], 4) for w in share}, "slowest_rank": {str(w): worst_rank[w] for w in worst_rank},
+            "mean_rank_share_ms": {str(w): round(mean_share[w], 4) for w in mean_share},
             "pct_of_linear": {str(w): round(100.0 * share[1] / (w * share[w]), 1) for w in share},
             "exchange_wire_ms_model": {str(w): round(wire[w], 4) for w in wire},
             "exchange_model": f"per peer: its compact tiles over one xGMI link at {link_gbs} GB/s x {eff} (assumed), peers in parallel; "
@@ -482,9 +488,10 @@ def main():
     torch.cuda.synchronize()
 
     if grouped:
-        my_ext = tiles.shard_ext(ext, rank, world, a.tile)
+        skew = tiles.balanced_skew(image, a.tile, world) if a.tile_skew < 0 else a.tile_skew
+        my_ext = tiles.shard_ext(ext, rank, world, a.tile, skew)
         # double-buffered asynchronous exchange: frame k's gather to rank 0 overlaps frame k+1's march
-        ex = tiles.FrameExchange(image, image, a.tile, torch.float32, dev, depth=2, dst=0)
+        ex = tiles.FrameExchange(image, image, a.tile, torch.float32, dev, depth=2, dst=0, skew=skew)
         local = ex.local(0)
     else:
         my_ext, ex = ext, None
@@ -603,7 +610,7 @@ def main():
                        + ("central-difference gradient + Blinn-Phong + " if not a.no_shade else "") + "ERT"
                        + ("" if world == 1 else f"; image fixed as N grows, tiles over {world} ranks"),
                        "math": a.math, "layout": a.layout, "intensityAlpha": a.alpha,
-                       "tiles": f"{a.tile}x{a.tile} round-robin over {world} rank(s)",
+                       "tiles": f"{a.tile}x{a.tile} dealt round-robin over {world} rank(s)" + (f", rows rotated by tileSkew {my_ext.get('tileSkew', 0)} (diagonal deal)" if grouped else ""),
                        "live_samples_per_frame": live, "shaded_samples_per_frame": shaded,
                        "nominal_samples_per_frame": image * image * a.march_steps,
                        "effective_Msamples_s_nominal": round(image * image * a.march_steps * a.steps / elapsed / 1e6, 1),

@@ -121,7 +121,12 @@ typedef struct MrirtRenderExt {
      * out[local_tile][tileSize][tileSize][4]; pitch is ignored.                            */
     uint32_t tileSize, tileRank, tileWorld;
     uint32_t kernelVariant;     /* 0 = library default; others select experimental kernels (bench/tests) */
-    uint32_t reserved[2];
+    /* Tile sharding, load balance: the dealt tile t sits at row ty = t / tilesX, column tx = (t % tilesX + tileSkew * ty) % tilesX
+     * (0: tx = t % tilesX, the plain row-major deal).  When tilesX is a multiple of tileWorld the plain deal hands every rank
+     * whole tile COLUMNS (rank = tx % world); a skew of (tilesX - 1) % tileWorld turns that into diagonals, rank = (tx + ty) % world,
+     * so every rank draws from every column and row of the image.  mrirt_detile takes the same value.                         */
+    uint32_t tileSkew;
+    uint32_t reserved;
 } MrirtRenderExt;
 
 /* Argument checks shared by every K1 entry point (MRIRT_ERR_ARG, nothing is launched): stepSize must be a
@@ -294,7 +299,7 @@ int mrirt_brats_kernel_family(const MrirtBratsParams* params, const MrirtRenderE
 int64_t mrirt_tiles_for_rank(uint32_t width, uint32_t height, uint32_t tileSize, uint32_t rank, uint32_t world);
 /* scatter gathered compact tile buffers [world][max_local][ts][ts][4] back into a pitch-linear frame */
 int mrirt_detile(const void* gathered, void* frame, uint32_t width, uint32_t height, int64_t pitch_px,
-                 uint32_t tileSize, uint32_t world, uint32_t outFormat, void* stream);
+                 uint32_t tileSize, uint32_t world, uint32_t tileSkew, uint32_t outFormat, void* stream);
 
 /* ------------------------------------------------------------------------------------ */
 /* INR forward (inr/inr/model.py:11-50,119-141; notebooks/neumors_inr.ipynb:1165-1178)   */

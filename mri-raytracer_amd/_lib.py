@@ -69,7 +69,7 @@ class RenderExt(C.Structure):
         ("ertOverride", u32), ("ertThreshold", f32),
         ("math", u32), ("outFormat", u32), ("layout", u32), ("labelLayout", u32),
         ("tileSize", u32), ("tileRank", u32), ("tileWorld", u32),
-        ("kernelVariant", u32), ("reserved", u32 * 2),
+        ("kernelVariant", u32), ("tileSkew", u32), ("reserved", u32),
     ]
 
 
@@ -284,7 +284,7 @@ def lib() -> C.CDLL:
     l.mrirt_render_sdf.argtypes = [C.POINTER(SdfParams), u32, u32, vp, i64, vp]
     l.mrirt_tiles_for_rank.argtypes = [u32, u32, u32, u32, u32]
     l.mrirt_tiles_for_rank.restype = i64
-    l.mrirt_detile.argtypes = [vp, vp, u32, u32, i64, u32, u32, u32, vp]
+    l.mrirt_detile.argtypes = [vp, vp, u32, u32, i64, u32, u32, u32, u32, vp]
     l.mrirt_inr_pack_bytes.argtypes = [C.POINTER(InrDesc)]
     l.mrirt_inr_pack_bytes.restype = i64
     l.mrirt_inr_pack_weights.argtypes = [C.POINTER(InrDesc), vp, vp, vp]

@@ -114,7 +114,7 @@ __device__ __forceinline__ uint32_t wave_max8(uint32_t v) { return 255u - wave_m
 // returns 0 from lanes that are switched off, which is why the skipping march keeps every lane of the wave in its
 // loops (finished rays ride along as `!alive`) instead of letting them exit.
 // MapWindow's index arithmetic (host + device: tests/native/index_harness.hip walks it under ASan / UBSan)
-MRIRT_HD uint32_t window_origin(bool towardsPlus, uint32_t lo, uint32_t hi) { return towardsPlus ? lo : (hi > 3u ? hi : 3u) - 3u; }
+MRIRT_HD uint32_t window_origin(bool towardsPlus, uint32_t lo, uint32_t hi) { return towardsPlus ? lo : max(hi, 3u) - 3u; }
 MRIRT_HD bool window_holds(uint32_t cx, uint32_t cy, uint32_t cz, uint32_t ox, uint32_t oy, uint32_t oz) {
     return (cx - ox) < 4u && (cy - oy) < 4u && (cz - oz) < 4u;
 }
@@ -123,9 +123,7 @@ MRIRT_HD uint32_t window_slot(uint32_t cx, uint32_t cy, uint32_t cz, uint32_t ox
 }
 // the macro cell lane `lane` fetches when the window moves to (ox, oy, oz): clamped into the map
 MRIRT_HD uint32_t window_fetch_index(uint32_t ox, uint32_t oy, uint32_t oz, uint32_t lane, uint32_t mX, uint32_t mY, uint32_t mZ, uint32_t mXY) {
-    const uint32_t gx = ox + (lane & 3u) < mX ? ox + (lane & 3u) : mX - 1u;
-    const uint32_t gy = oy + ((lane >> 2) & 3u) < mY ? oy + ((lane >> 2) & 3u) : mY - 1u;
-    const uint32_t gz = oz + (lane >> 4) < mZ ? oz + (lane >> 4) : mZ - 1u;
+    const uint32_t gx = min(ox + (lane & 3u), mX - 1u), gy = min(oy + ((lane >> 2) & 3u), mY - 1u), gz = min(oz + (lane >> 4), mZ - 1u);
     return gx + gy * mX + gz * mXY;
 }
 

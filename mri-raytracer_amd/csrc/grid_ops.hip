@@ -99,10 +99,10 @@ __global__ __launch_bounds__(256) void vga_build_kernel(const float* __restrict_
 template <bool HALF>
 __global__ __launch_bounds__(256) void detile_kernel(const void* __restrict__ gathered, void* __restrict__ frame,
                                                      uint32_t width, uint32_t height, int64_t pitch,
-                                                     uint32_t ts, uint32_t world, uint32_t tilesX, uint32_t maxLocal) {
+                                                     uint32_t ts, uint32_t world, uint32_t tilesX, uint32_t maxLocal, uint32_t skew) {
     const uint32_t px = blockIdx.x * 16 + (threadIdx.x & 15u), py = blockIdx.y * 16 + (threadIdx.x >> 4);
     if (px >= width || py >= height) return;
-    const uint32_t t = (py / ts) * tilesX + px / ts;
+    const uint32_t t = tile_dealt_index(px / ts, py / ts, tilesX, skew);
     const uint32_t rank = t % world, lt = t / world;
     const int64_t src = (((int64_t)rank * maxLocal + lt) * ts + (py % ts)) * ts + (px % ts);
     const int64_t dst = (int64_t)py * pitch + px;
@@ -362,7 +362,7 @@ extern "C" int64_t mrirt_tiles_for_rank(uint32_t width, uint32_t height, uint32_
 }
 
 extern "C" int mrirt_detile(const void* gathered, void* frame, uint32_t width, uint32_t height, int64_t pitch_px,
-                            uint32_t tileSize, uint32_t world, uint32_t outFormat, void* stream) {
+                            uint32_t tileSize, uint32_t world, uint32_t tileSkew, uint32_t outFormat, void* stream) {
     if (!gathered || !frame) return MRIRT_ERR_NULL;
     if (width == 0 || height == 0) return MRIRT_ERR_DIMS;
     if (tileSize == 0 || world == 0 || pitch_px < (int64_t)width) return MRIRT_ERR_ARG;
@@ -372,9 +372,9 @@ extern "C" int mrirt_detile(const void* gathered, void* frame, uint32_t width, u
     const dim3 grid((width + 15) / 16, (height + 15) / 16), block(256);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (outFormat == MRIRT_OUT_RGBA16F)
-        hipLaunchKernelGGL((detile_kernel<true>), grid, block, 0, s, gathered, frame, width, height, pitch_px, tileSize, world, tilesX, maxLocal);
+        hipLaunchKernelGGL((detile_kernel<true>), grid, block, 0, s, gathered, frame, width, height, pitch_px, tileSize, world, tilesX, maxLocal, tileSkew);
     else
-        hipLaunchKernelGGL((detile_kernel<false>), grid, block, 0, s, gathered, frame, width, height, pitch_px, tileSize, world, tilesX, maxLocal);
+        hipLaunchKernelGGL((detile_kernel<false>), grid, block, 0, s, gathered, frame, width, height, pitch_px, tileSize, world, tilesX, maxLocal, tileSkew);
     MRIRT_HIP(hipGetLastError());
     return MRIRT_OK;
 }

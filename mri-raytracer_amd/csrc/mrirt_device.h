@@ -320,6 +320,7 @@ struct PixelMap {
     uint32_t blocksX, numBlocks;       // 16x16-pixel workgroups over the part of the image this call renders
     uint32_t chunk;                    // ceil(numBlocks / 8): logical ids one XCD owns
     uint32_t tileSize, tileRank, tileWorld, tilesX;   // tileSize == 0: whole frame
+    uint32_t tileSkew;                 // dealt tile t -> column (t % tilesX + tileSkew * row) % tilesX (MrirtRenderExt::tileSkew)
     uint32_t laneOrder;                // 0 row-major 8x8 packet, 1 Morton (2x2 pixel quads per 4 lanes)
     uint32_t blockPx;                  // 16: 256-thread workgroups (2x2 packets); 8: one packet per workgroup
     uint32_t bandBlocks;               // whole-frame XCD interleave: workgroups per band (0 = contiguous runs)
@@ -332,6 +333,16 @@ struct PixelMap {
 // Grid is chunk*8 workgroups.  Returns 0: this lane has no pixel (whole workgroups past
 // numBlocks, or whole-frame lanes beyond the image edge); 1: march pixel (px,py) and store at
 // outIndex; 2: (tile mode) a compact-buffer slot outside the image: store background only.
+// tile sharding: where the dealt tile t sits in the image, and which dealt index a tile position has (inverse)
+MRIRT_HD void tile_position(uint32_t t, uint32_t tilesX, uint32_t skew, uint32_t& tx, uint32_t& ty) {
+    ty = t / tilesX;
+    tx = (t % tilesX + (uint32_t)(((uint64_t)skew * ty) % tilesX)) % tilesX;
+}
+MRIRT_HD uint32_t tile_dealt_index(uint32_t tx, uint32_t ty, uint32_t tilesX, uint32_t skew) {
+    const uint32_t rot = (uint32_t)(((uint64_t)skew * ty) % tilesX);
+    return ty * tilesX + (tx + tilesX - rot) % tilesX;
+}
+
 MRIRT_HD int map_pixel_at(const PixelMap& m, uint32_t b, uint32_t tid, uint32_t& px, uint32_t& py, int64_t& outIndex) {
     uint32_t logical;
     if (m.bandBlocks != 0) {
@@ -368,7 +379,8 @@ MRIRT_HD int map_pixel_at(const PixelMap& m, uint32_t b, uint32_t tid, uint32_t&
         uint32_t bpr = m.tileSize / m.blockPx, bpt = bpr * bpr;
         uint32_t lt = logical / bpt, sb = logical % bpt;
         uint32_t t = m.tileRank + lt * m.tileWorld;
-        uint32_t tx = t % m.tilesX, ty = t / m.tilesX;
+        uint32_t tx, ty;
+        tile_position(t, m.tilesX, m.tileSkew, tx, ty);
         uint32_t ix = (sb % bpr) * m.blockPx + lx, iy = (sb / bpr) * m.blockPx + ly;
         px = tx * m.tileSize + ix; py = ty * m.tileSize + iy;
         outIndex = ((int64_t)lt * m.tileSize + iy) * m.tileSize + ix;

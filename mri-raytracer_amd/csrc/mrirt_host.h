@@ -83,6 +83,7 @@ inline int fill_pixel_map(PixelMap& m, uint32_t width, uint32_t height, int64_t 
     m.tileSize = ext ? ext->tileSize : 0u;
     m.tileRank = ext ? ext->tileRank : 0u;
     m.tileWorld = ext ? ext->tileWorld : 0u;
+    m.tileSkew = ext ? ext->tileSkew : 0u;
     m.laneOrder = laneOrder;
     m.blockPx = blockPx;
     if (m.tileSize == 0) {

@@ -21,7 +21,7 @@ EXT_DEFAULTS: Dict[str, Any] = dict(
     outFormat="rgba32f",          # "rgba32f" | "rgba16f" (the reference's texture format)
     layout="linear",              # intensity grids: "linear" | "brick" | "vg" | "quad" | "vga"
     labelLayout="linear",         # labels / preds: "linear" | "brick" | "labcell" (both overlays per cell: upload_label_cells)
-    tileSize=0, tileRank=0, tileWorld=0,
+    tileSize=0, tileRank=0, tileWorld=0, tileSkew=0,
     kernelVariant=0,
 )
 
@@ -90,6 +90,7 @@ def render_ext(ext: Optional[Mapping[str, Any]] = None) -> _lib.RenderExt:
     s.math, s.outFormat, s.layout = _MATH[e["math"]], _FMT[e["outFormat"]], _LAYOUT[e["layout"]]
     s.labelLayout = _LAYOUT[e["labelLayout"]]
     s.tileSize, s.tileRank, s.tileWorld = int(e["tileSize"]), int(e["tileRank"]), int(e["tileWorld"])
+    s.tileSkew = int(e["tileSkew"])
     s.kernelVariant = int(e["kernelVariant"])
     return s
 

@@ -517,12 +517,13 @@ def render_sdf(params: Mapping[str, Any], eye, U, V, W, width: int, height: int,
 
 
 def detile(gathered: torch.Tensor, width: int, height: int, tile: int, world: int,
-           out: Optional[torch.Tensor] = None, stream=None) -> torch.Tensor:
-    """[world, max_local, ts, ts, 4] compact tiles -> (H, W, 4) frame (csrc/grid_ops.hip)."""
+           out: Optional[torch.Tensor] = None, stream=None, skew: int = 0) -> torch.Tensor:
+    """[world, max_local, ts, ts, 4] compact tiles -> (H, W, 4) frame (csrc/grid_ops.hip); ``skew`` = the ``tileSkew`` the
+    tiles were rendered with."""
     half = gathered.dtype == torch.float16
     if out is None:
         out = torch.empty((height, width, 4), dtype=gathered.dtype, device=gathered.device)
-    rc = _lib.lib().mrirt_detile(_ptr(gathered), _ptr(out), width, height, out.stride(0) // 4, tile, world,
+    rc = _lib.lib().mrirt_detile(_ptr(gathered), _ptr(out), width, height, out.stride(0) // 4, tile, world, int(skew),
                                  _lib.OUT_RGBA16F if half else _lib.OUT_RGBA32F, _stream_ptr(stream))
     _lib.check(rc, "mrirt_detile")
     return out

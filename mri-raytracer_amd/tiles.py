@@ -30,39 +30,51 @@ def local_tile_count(width: int, height: int, tile: int, rank: int, world: int) 
     return (n - rank + world - 1) // world if n > rank else 0
 
 
-def tile_origin(tile_id: int, width: int, tile: int):
+def tile_origin(tile_id: int, width: int, tile: int, skew: int = 0):
+    """(x0, y0) of the dealt tile ``tile_id`` (MrirtRenderExt::tileSkew: row ty is rotated by skew * ty columns)."""
     tiles_x = (width + tile - 1) // tile
-    return (tile_id % tiles_x) * tile, (tile_id // tiles_x) * tile      # (x0, y0)
+    ty = tile_id // tiles_x
+    tx = (tile_id % tiles_x + (skew * ty) % tiles_x) % tiles_x
+    return tx * tile, ty * tile
 
 
-def shard_ext(ext: Optional[Mapping[str, Any]], rank: int, world: int, tile: int = DEFAULT_TILE) -> Dict[str, Any]:
+def balanced_skew(width: int, tile: int, world: int) -> int:
+    """The ``tileSkew`` that deals tiles to ranks along diagonals: rank(tx, ty) = (tx + ty) mod world.  With the plain row-major
+    deal rank = (tx + ty * tilesX) mod world, which for tilesX a multiple of world (2048 px / 64 px = 32 columns over 8 ranks)
+    gives every rank whole tile COLUMNS — the ranks that draw the centre columns march the long rays (measured on config 4:
+    slowest rank 0.593 ms against 0.434 for an eighth of the frame).  (tilesX - skew) mod world = 1 is the diagonal deal."""
+    tiles_x = (width + tile - 1) // tile
+    return (tiles_x - 1) % world if world > 1 else 0
+
+
+def shard_ext(ext: Optional[Mapping[str, Any]], rank: int, world: int, tile: int = DEFAULT_TILE, skew: int = 0) -> Dict[str, Any]:
     """Render-extension dict that makes render_brats/render_volume_u8 produce this rank's tiles."""
     e = dict(ext or {})
-    e.update(tileSize=tile, tileRank=rank, tileWorld=world)
+    e.update(tileSize=tile, tileRank=rank, tileWorld=world, tileSkew=skew)
     return e
 
 
-def assemble_frame(gathered: torch.Tensor, width: int, height: int, tile: int, world: int) -> torch.Tensor:
+def assemble_frame(gathered: torch.Tensor, width: int, height: int, tile: int, world: int, skew: int = 0) -> torch.Tensor:
     """[world, max_local, tile, tile, 4] -> (H, W, 4).  Device tensors go through the HIP
     de-tiling kernel; host tensors (gloo tests, host read-back) through plain indexing."""
     if gathered.is_cuda:
         from .render import detile
-        return detile(gathered.contiguous(), width, height, tile, world)
+        return detile(gathered.contiguous(), width, height, tile, world, skew=skew)
     tiles_x, tiles_y = (width + tile - 1) // tile, (height + tile - 1) // tile
     frame = gathered.new_empty((tiles_y * tile, tiles_x * tile, 4))
     for t in range(tiles_x * tiles_y):
-        x0, y0 = tile_origin(t, width, tile)
+        x0, y0 = tile_origin(t, width, tile, skew)
         frame[y0:y0 + tile, x0:x0 + tile] = gathered[t % world, t // world]
     return frame[:height, :width].contiguous()
 
 
 def gather_frame(local_tiles: torch.Tensor, width: int, height: int, tile: int = DEFAULT_TILE,
-                 group=None, dst: int = 0, all_ranks: bool = False) -> Optional[torch.Tensor]:
+                 group=None, dst: int = 0, all_ranks: bool = False, skew: int = 0) -> Optional[torch.Tensor]:
     """The one exchange step.  ``local_tiles`` is this rank's compact buffer; returns the full
     frame on ``dst`` (on every rank when ``all_ranks``), None elsewhere.  Ranks may own unequal
     tile counts (off by at most one): buffers are padded to rank 0's count for the collective."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return assemble_frame(local_tiles.unsqueeze(0), width, height, tile, 1)
+        return assemble_frame(local_tiles.unsqueeze(0), width, height, tile, 1, skew)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     max_local = local_tile_count(width, height, tile, 0, world)
     send = local_tiles
@@ -74,13 +86,13 @@ def gather_frame(local_tiles: torch.Tensor, width: int, height: int, tile: int =
         # concatenated along dim 0 (the form every backend accepts), viewed as [world, max_local, ...]
         buf = send.new_empty((world * send.shape[0],) + tuple(send.shape[1:]))
         dist.all_gather_into_tensor(buf, send, group=group)
-        return assemble_frame(buf.view((world,) + tuple(send.shape)), width, height, tile, world)
+        return assemble_frame(buf.view((world,) + tuple(send.shape)), width, height, tile, world, skew)
     # ``dst`` is a rank OF THE GROUP (like ``rank`` above); torch's collectives take the global rank
     gdst = dist.get_global_rank(group, dst) if group is not None else dst
     if rank == dst:
         buf = send.new_empty((world,) + tuple(send.shape))
         dist.gather(send, list(buf.unbind(0)), dst=gdst, group=group)
-        return assemble_frame(buf, width, height, tile, world)
+        return assemble_frame(buf, width, height, tile, world, skew)
     dist.gather(send, None, dst=gdst, group=group)
     return None
 
@@ -101,8 +113,8 @@ class FrameExchange:
     * ``dst=None``: every rank needs the frame — an all-gather (N times the bytes on the wire)."""
 
     def __init__(self, width: int, height: int, tile: int, dtype: torch.dtype, device, group=None,
-                 depth: int = 2, dst: Optional[int] = 0):
-        self.w, self.h, self.tile, self.group, self.dst = width, height, tile, group, dst
+                 depth: int = 2, dst: Optional[int] = 0, skew: int = 0):
+        self.w, self.h, self.tile, self.group, self.dst, self.skew = width, height, tile, group, dst, skew
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.n_local = local_tile_count(width, height, tile, self.rank, self.world)
@@ -140,17 +152,19 @@ class FrameExchange:
         if not self.receives:
             return None
         g = self._recv[i].view(self.world, self.max_local, self.tile, self.tile, 4)
-        return assemble_frame(g, self.w, self.h, self.tile, self.world)
+        return assemble_frame(g, self.w, self.h, self.tile, self.world, self.skew)
 
 
 def render_brats_sharded(params, intensities: Sequence, labels=None, preds=None, ext=None,
                          tile: int = DEFAULT_TILE, group=None, dst: int = 0, all_ranks: bool = False):
-    """K1 across the process group: render this rank's tiles, then gather (see module docstring)."""
+    """K1 across the process group: render this rank's tiles (dealt along diagonals: balanced_skew), then gather (see module
+    docstring)."""
     from .render import render_brats
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     if world == 1:
         return render_brats(params, intensities, labels, preds, ext=ext)
-    local = render_brats(params, intensities, labels, preds, ext=shard_ext(ext, rank, world, tile))
     w, h = int(params["imageSize"][0]), int(params["imageSize"][1])
-    return gather_frame(local, w, h, tile, group=group, dst=dst, all_ranks=all_ranks)
+    skew = balanced_skew(w, tile, world)
+    local = render_brats(params, intensities, labels, preds, ext=shard_ext(ext, rank, world, tile, skew))
+    return gather_frame(local, w, h, tile, group=group, dst=dst, all_ranks=all_ranks, skew=skew)

@@ -383,11 +383,24 @@ int main() {
         memset(&e, 0, sizeof e);
         e.layout = MRIRT_LAYOUT_VGA; e.shadeMode = 1;
         for (uint32_t world : { 1u, 2u, 3u, 8u })
-            for (uint32_t ts : { 64u, 32u }) {
-                e.tileSize = ts; e.tileWorld = world; e.tileRank = world - 1;
-                pixel_map_checks(p, &e, 2048);
+            for (uint32_t ts : { 64u, 32u })
+                for (uint32_t skew : { 0u, 7u, 1u, 31u, 1000003u }) {
+                    e.tileSize = ts; e.tileWorld = world; e.tileRank = world - 1; e.tileSkew = skew;
+                    pixel_map_checks(p, &e, 2048);
+                }
+        // the skewed deal is a permutation of the tile grid, and tile_dealt_index inverts tile_position (the de-tiling kernel's side)
+        for (uint32_t tilesX : { 1u, 3u, 32u, 33u })
+            for (uint32_t skew : { 0u, 1u, 7u, 31u, 4000000000u }) {
+                std::vector<uint8_t> hit(tilesX * 5u, 0);
+                for (uint32_t t = 0; t < tilesX * 5u; ++t) {
+                    uint32_t tx, ty;
+                    tile_position(t, tilesX, skew, tx, ty);
+                    CHECK(tx < tilesX && ty < 5u, "tile %u lands outside the grid", t);
+                    if (tx < tilesX && ty < 5u) { CHECK(!hit[ty * tilesX + tx], "two tiles on one position"); hit[ty * tilesX + tx] = 1; }
+                    CHECK(tile_dealt_index(tx, ty, tilesX, skew) == t, "tile_dealt_index does not invert tile_position (t %u skew %u tilesX %u)", t, skew, tilesX);
+                }
             }
-        e.tileSize = 0;
+        e.tileSize = 0; e.tileSkew = 0; e.kernelVariant = 0;
         p.imageSize[0] = 1024; p.imageSize[1] = 1024;
         pixel_map_checks(p, &e, 1024);
         p.imageSize[0] = 203; p.imageSize[1] = 151;

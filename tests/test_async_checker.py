@@ -102,3 +102,14 @@ def test_the_hazard_is_found_across_a_branch_and_for_compare_and_carry_writers()
     assert len(chk.hazard_scan("k", listing(carry))) == 1
     vcc = [("v_cmp_eq_u32_e32 vcc, 1, v7", 4), ("global_load_dword v1, v2, vcc", 8), ("s_endpgm", 4)]
     assert len(chk.hazard_scan("k", listing(vcc))) == 1
+
+
+def test_a_scalar_redefinition_between_the_valu_write_and_the_load_clears_the_register():
+    """What the fixed gathers look like when the allocator reuses a mask register for the copied base: the v_cmp's result is dead,
+    the s_mov_b64 defines the pair the load reads."""
+    rows = [("v_cmp_gt_f32_e64 s[6:7], s29, 0", 8), ("v_cndmask_b32_e64 v9, v1, v2, s[6:7]", 8), ("s_mov_b64 s[6:7], s[40:41]", 4),
+            ("global_load_dwordx4 v[22:25], v18, s[6:7]", 8), ("s_endpgm", 4)]
+    assert chk.hazard_scan("k", listing(rows)) == []
+    # ... but only for the registers it defines
+    rows[2] = ("s_mov_b32 s6, s40", 4)
+    assert len(chk.hazard_scan("k", listing(rows))) == 1

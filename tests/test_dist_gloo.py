@@ -35,17 +35,18 @@ def _worker(rank, world, port, w, h, tile, all_ranks, q):
         padded[..., 3] = 1.0
         padded[:h, :w] = full
         n_local = tiles.local_tile_count(w, h, tile, rank, world)
+        skew = tiles.balanced_skew(w, tile, world)                 # the diagonal deal the sharded render uses
         local = torch.empty((n_local, tile, tile, 4))
         for lt in range(n_local):
-            x0, y0 = tiles.tile_origin(rank + lt * world, w, tile)
+            x0, y0 = tiles.tile_origin(rank + lt * world, w, tile, skew)
             local[lt] = torch.from_numpy(padded[y0:y0 + tile, x0:x0 + tile])
-        frame = tiles.gather_frame(local, w, h, tile, dst=0, all_ranks=all_ranks)
+        frame = tiles.gather_frame(local, w, h, tile, dst=0, all_ranks=all_ranks, skew=skew)
         if all_ranks or rank == 0:
             ok = frame is not None and torch.equal(frame, torch.from_numpy(full))
         else:
             ok = frame is None
         # the frame-loop form: double-buffered asynchronous exchange, 5 frames in flight order
-        ex = tiles.FrameExchange(w, h, tile, torch.float32, "cpu", depth=2, dst=0)
+        ex = tiles.FrameExchange(w, h, tile, torch.float32, "cpu", depth=2, dst=0, skew=skew)
         assert ex.n_local == n_local
         got = []
         for f in range(5):

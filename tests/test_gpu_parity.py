@@ -446,15 +446,21 @@ def test_c4_full_size_tiles_over_eight_ranks(env, layout):
     ext = dict(synth.SHADE_EXT, layout=layout)
     whole, sw = mrirt.render_brats(p, [g], ext=ext, stats=True)
     max_local = tiles.local_tile_count(image, image, tile, 0, world)
-    gathered = torch.zeros((world, max_local, tile, tile, 4), device="cuda")
-    live = shaded = 0
-    for r in range(world):
-        part, st = mrirt.render_brats(p, [g], ext=tiles.shard_ext(ext, r, world, tile), stats=True)
-        assert part.shape == (tiles.local_tile_count(image, image, tile, r, world), tile, tile, 4)
-        gathered[r, :part.shape[0]] = part
-        live, shaded = live + st["live_samples"], shaded + st["shaded_samples"]
-    assert torch.equal(mrirt.detile(gathered, image, image, tile, world), whole)
-    assert live == sw["live_samples"] and shaded == sw["shaded_samples"]
+    # the deal bench.py --gpus N uses (tiles along diagonals: tiles.balanced_skew), and the plain row-major one
+    for skew in (tiles.balanced_skew(image, tile, world), 0):
+        gathered = torch.zeros((world, max_local, tile, tile, 4), device="cuda")
+        live = shaded = 0
+        per_rank = []
+        for r in range(world):
+            part, st = mrirt.render_brats(p, [g], ext=tiles.shard_ext(ext, r, world, tile, skew), stats=True)
+            assert part.shape == (tiles.local_tile_count(image, image, tile, r, world), tile, tile, 4)
+            gathered[r, :part.shape[0]] = part
+            live, shaded = live + st["live_samples"], shaded + st["shaded_samples"]
+            per_rank.append(st["live_samples"])
+        assert torch.equal(mrirt.detile(gathered, image, image, tile, world, skew=skew), whole), skew
+        assert live == sw["live_samples"] and shaded == sw["shaded_samples"]
+        if skew:          # the diagonal deal balances the ranks' work: within 3 % of an eighth of the frame each
+            assert max(per_rank) <= 1.03 * live / world, per_rank
     assert 0 < live < image * image * steps
     # ... and the frame itself against the oracle: 128 rows through the long centre rays and 32 at the top edge of the
     # 2048^2 image (C4 used to be compared only with itself)

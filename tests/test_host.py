@@ -119,7 +119,19 @@ def test_tile_bookkeeping():
         assert counts == [lib.mrirt_tiles_for_rank(w, h, t, r, world) for r in range(world)]
     assert tiles.tile_origin(5, 150, 32) == (0, 32) and tiles.tile_origin(4, 150, 32) == (128, 0)
     e = tiles.shard_ext(dict(math="fast"), 2, 8)
-    assert e == dict(math="fast", tileSize=64, tileRank=2, tileWorld=8)
+    assert e == dict(math="fast", tileSize=64, tileRank=2, tileWorld=8, tileSkew=0)
+    # the diagonal deal (tileSkew): a permutation of every tile row, rank(tx, ty) = (tx + ty) mod world when tilesX % world == 0
+    for (w, t, world) in ((2048, 64, 8), (2048, 32, 4), (150, 32, 3), (64, 64, 1)):
+        skew = tiles.balanced_skew(w, t, world)
+        tiles_x = (w + t - 1) // t
+        seen = set()
+        for tid in range(tiles_x * 6):
+            x0, y0 = tiles.tile_origin(tid, w, t, skew)
+            assert 0 <= x0 < tiles_x * t and y0 == (tid // tiles_x) * t and (x0, y0) not in seen
+            seen.add((x0, y0))
+            if tiles_x % world == 0:
+                assert tid % world == (x0 // t + y0 // t) % world
+    assert tiles.balanced_skew(2048, 64, 8) == 7 and tiles.balanced_skew(2048, 64, 1) == 0
 
 
 def test_assemble_frame_on_host_tensors():
@@ -129,11 +141,12 @@ def test_assemble_frame_on_host_tensors():
     frame = torch.arange(ty * t * tx * t * 4, dtype=torch.float32).reshape(ty * t, tx * t, 4)
     maxl = tiles.local_tile_count(w, h, t, 0, world)
     g = torch.zeros(world, maxl, t, t, 4)
-    for tid in range(tx * ty):
-        x0, y0 = tiles.tile_origin(tid, w, t)
-        g[tid % world, tid // world] = frame[y0:y0 + t, x0:x0 + t]
-    out = tiles.assemble_frame(g, w, h, t, world)
-    assert out.shape == (h, w, 4) and torch.equal(out, frame[:h, :w])
+    for skew in (0, 2, 4):
+        for tid in range(tx * ty):
+            x0, y0 = tiles.tile_origin(tid, w, t, skew)
+            g[tid % world, tid // world] = frame[y0:y0 + t, x0:x0 + t]
+        out = tiles.assemble_frame(g, w, h, t, world, skew)
+        assert out.shape == (h, w, 4) and torch.equal(out, frame[:h, :w]), skew
 
 
 def test_no_cpu_fallback():

@@ -179,6 +179,21 @@ def valu_sgpr_writes(text):
     return w
 
 
+SALU_NO_DST = ("s_cmp", "s_bitcmp", "s_setprio", "s_waitcnt", "s_nop", "s_barrier", "s_cbranch", "s_branch", "s_endpgm", "s_sleep",
+               "s_sendmsg", "s_store", "s_dcache", "s_icache", "s_setreg", "s_sethalt", "s_trap", "s_inst_prefetch", "s_clause",
+               "s_setpc", "s_swappc", "s_rfe", "s_ttrace", "s_incperflevel", "s_decperflevel", "s_set_gpr_idx", "s_atc_probe",
+               "s_scratch_store", "s_buffer_store")
+
+
+def scalar_sgpr_writes(text):
+    """SGPRs a SCALAR instruction (SALU / SMEM load) defines: its first operand.  A vector-memory read of an SGPR a scalar
+    instruction wrote last has no hazard, whatever a VALU instruction wrote into it earlier."""
+    mn = text.split()[0]
+    if not mn.startswith("s_") or mn.startswith(SALU_NO_DST) or " " not in text:
+        return set()
+    return sregs(text.split(None, 1)[1].split(",")[0])
+
+
 def hazard_scan(name, lines):
     """[(line_no, vmem instruction, writer instruction, wait states)] for every vector-memory instruction that reads an SGPR a
     VALU instruction wrote fewer than HAZARD_WAIT_STATES wait states earlier, on ANY path through the function."""
@@ -206,22 +221,22 @@ def hazard_scan(name, lines):
         need = sregs(m.group(2))
         if not need:
             continue
-        # walk backwards over every path until HAZARD_WAIT_STATES wait states have been seen
-        stack, seen, hit = [(p, 0) for p in preds[i]], set(), None
+        # walk backwards over every path until HAZARD_WAIT_STATES wait states have been seen; registers a scalar instruction
+        # defined on the way are no longer looked for on that path
+        stack, seen, hit = [(p, 0, frozenset(need)) for p in preds[i]], set(), None
         while stack and hit is None:
-            j, ws = stack.pop()
-            if (j, ws) in seen or ws >= HAZARD_WAIT_STATES:
+            j, ws, want = stack.pop()
+            if (j, ws, want) in seen or ws >= HAZARD_WAIT_STATES or not want:
                 continue
-            seen.add((j, ws))
+            seen.add((j, ws, want))
             t = ins[j][3]
-            if valu_sgpr_writes(t) & need:
+            if valu_sgpr_writes(t) & want:
                 hit = (no, text, t, ws)
                 break
-            if t.startswith("s_waitcnt") or t.startswith("s_barrier"):
-                pass                                      # (wait states still only count issue slots)
-            step = int(t.split()[1]) + 1 if t.startswith("s_nop") else 1
+            want = want - scalar_sgpr_writes(t)
+            step = int(t.split()[1]) + 1 if t.startswith("s_nop") else 1       # (s_waitcnt counts as one issue slot, like any instruction)
             for p in preds[j]:
-                stack.append((p, ws + step))
+                stack.append((p, ws + step, want))
         if hit:
             found.append(hit)
     return found
