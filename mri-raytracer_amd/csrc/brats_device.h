@@ -145,10 +145,22 @@ template <bool SHADE> struct Taps<2, SHADE> {        // VG: 8 x (v, dx, dy, dz)
     // the same eight gathers as inline asm (issue_async) and the wait that retires them (arrive): see async_load_vec4
     __device__ __forceinline__ void issue_async(const void* __restrict__ vbuf, const CellOffsets& k) {
         const uint32_t o10 = k.o + k.dx, o01 = k.o + k.dy, o11 = o10 + k.dy;
-        async_load_vec4(c[0], vbuf, k.o);        async_load_vec4(c[1], vbuf, o10);
-        async_load_vec4(c[2], vbuf, o01);        async_load_vec4(c[3], vbuf, o11);
-        async_load_vec4(c[4], vbuf, k.o + k.dz); async_load_vec4(c[5], vbuf, o10 + k.dz);
-        async_load_vec4(c[6], vbuf, o01 + k.dz); async_load_vec4(c[7], vbuf, o11 + k.dz);
+        // ONE statement: the base copied once by a scalar move (async_load_vec4, point 4), then the eight gathers.  The
+        // destinations are early-clobber: a statement's outputs may otherwise share registers with its inputs, and these
+        // are written (asynchronously) while later gathers of the statement still have their address to read.
+        f32x4 t0, t1, t2, t3, t4, t5, t6, t7;
+        sbase_t b;
+        asm volatile("s_mov_b64 %8, %17\n\t"
+                     "global_load_dwordx4 %0, %9, %8\n\tglobal_load_dwordx4 %1, %10, %8\n\t"
+                     "global_load_dwordx4 %2, %11, %8\n\tglobal_load_dwordx4 %3, %12, %8\n\t"
+                     "global_load_dwordx4 %4, %13, %8\n\tglobal_load_dwordx4 %5, %14, %8\n\t"
+                     "global_load_dwordx4 %6, %15, %8\n\tglobal_load_dwordx4 %7, %16, %8"
+                     : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7), "=&s"(b)
+                     : "v"(k.o << 4), "v"(o10 << 4), "v"(o01 << 4), "v"(o11 << 4),
+                       "v"((k.o + k.dz) << 4), "v"((o10 + k.dz) << 4), "v"((o01 + k.dz) << 4), "v"((o11 + k.dz) << 4), "s"(vbuf));
+        c[0] = __builtin_bit_cast(float4, t0); c[1] = __builtin_bit_cast(float4, t1); c[2] = __builtin_bit_cast(float4, t2);
+        c[3] = __builtin_bit_cast(float4, t3); c[4] = __builtin_bit_cast(float4, t4); c[5] = __builtin_bit_cast(float4, t5);
+        c[6] = __builtin_bit_cast(float4, t6); c[7] = __builtin_bit_cast(float4, t7);
     }
     template <int YOUNGER>
     __device__ __forceinline__ void arrive() {
@@ -235,8 +247,12 @@ template <> struct Taps<3, false> {                  // QUAD: the z and z+1 xy-q
         q1 = load_vec4<WIDE>(vbuf, k.o + k.dz);
     }
     __device__ __forceinline__ void issue_async(const void* __restrict__ vbuf, const CellOffsets& k) {
-        async_load_vec4(q0, vbuf, k.o);
-        async_load_vec4(q1, vbuf, k.o + k.dz);
+        f32x4 t0, t1;                                   // one statement, the base copied once: see Taps<2>::issue_async
+        sbase_t b;
+        asm volatile("s_mov_b64 %2, %5\n\tglobal_load_dwordx4 %0, %3, %2\n\tglobal_load_dwordx4 %1, %4, %2"
+                     : "=&v"(t0), "=&v"(t1), "=&s"(b) : "v"(k.o << 4), "v"((k.o + k.dz) << 4), "s"(vbuf));
+        q0 = __builtin_bit_cast(float4, t0);
+        q1 = __builtin_bit_cast(float4, t1);
     }
     template <bool STRICT>
     __device__ __forceinline__ void eval(const Cell& s, float& v, float*) const {
@@ -328,8 +344,13 @@ template <> struct Taps<0, false> {
         }
     }
     __device__ __forceinline__ void issue_async(const void* __restrict__ vbuf, const CellOffsets& k) {   // k in ELEMENTS (floats); grid < 4 GiB
-        async_load_pair(p[0], vbuf, k.o << 2);           async_load_pair(p[1], vbuf, (k.o + k.dy) << 2);
-        async_load_pair(p[2], vbuf, (k.o + k.dz) << 2);  async_load_pair(p[3], vbuf, (k.o + k.dy + k.dz) << 2);
+        f32x2 t0, t1, t2, t3;                           // one statement, the base copied once: see Taps<2>::issue_async
+        sbase_t b;
+        asm volatile("s_mov_b64 %4, %9\n\tglobal_load_dwordx2 %0, %5, %4\n\tglobal_load_dwordx2 %1, %6, %4\n\t"
+                     "global_load_dwordx2 %2, %7, %4\n\tglobal_load_dwordx2 %3, %8, %4"
+                     : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&s"(b)
+                     : "v"(k.o << 2), "v"((k.o + k.dy) << 2), "v"((k.o + k.dz) << 2), "v"((k.o + k.dy + k.dz) << 2), "s"(vbuf));
+        p[0] = t0; p[1] = t1; p[2] = t2; p[3] = t3;
     }
     template <bool STRICT>
     __device__ __forceinline__ void eval(const Cell& s, float& v, float*) const {
