@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256, 1) void kpass(const uint4* __restrict__ w, uns
     f32x16 acc[2] = { (f32x16)(0.0f), (f32x16)(0.0f) }, other = (f32x16)(0.25f);
     typedef __attribute__((address_space(3))) u32x4 lq;
     lq* base = (lq*)lds + lane;
-    float keep = 0.0f;
+    float keep = 0.0f, keep2 = 0.0f;
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     f32x4 bq = (f32x4)(0.0f);
     unsigned long long t0 = __builtin_amdgcn_s_memtime();
@@ -188,6 +188,22 @@ __global__ __launch_bounds__(256, 1) void kpass(const uint4* __restrict__ w, uns
                         }
                     }
                 }
+                if (VARIANT == 8 || VARIANT == 9 || VARIANT == 10) {
+                    // 8: the weight-stationary kernel's own order — one v_sin per step and, on odd steps, the packed convert of the
+                    //    value the sine has JUST produced (a dependent instruction behind a transcendental: with one wave per SIMD
+                    //    nothing else can issue while it waits);
+                    // 9: software-pipelined — the convert takes the pair whose sines were issued two and three steps earlier;
+                    // 10: as 9 with the sine of step ks issued BEFORE the step's LDS read.
+                    f32x16& src = acc[p ^ 1];
+                    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+                    if (ks == 0) asm volatile("s_nop 15" : "+v"(src));
+                    src[ks] = __builtin_amdgcn_sinf(src[ks]);
+                    if (VARIANT == 8) {
+                        if (ks & 1) { bf2 pk = { (__bf16)src[ks - 1], (__bf16)src[ks] }; keep += __builtin_bit_cast(float, pk); }
+                    } else {
+                        if (ks & 1) { const int a = (ks + 13) & 15, b = (ks + 14) & 15; bf2 pk = { (__bf16)src[a], (__bf16)src[b] }; keep2 += __builtin_bit_cast(float, pk); }
+                    }
+                }
                 if (VARIANT != 1 && VARIANT < 4 && ks >= 2 && ks <= 9) {
                     f32x16& src = VARIANT == 2 ? other : acc[p ^ 1];
                     if (ks == 2) asm volatile("s_nop 15" : "+v"(src));
@@ -203,7 +219,7 @@ __global__ __launch_bounds__(256, 1) void kpass(const uint4* __restrict__ w, uns
     }
     unsigned long long t1 = __builtin_amdgcn_s_memtime();
     if (lane == 0) out[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
-    float s = keep;
+    float s = keep + keep2;
     for (int i = 0; i < 16; ++i) s += acc[0][i] + acc[1][i] + other[i];
     sink[blockIdx.x * 256 + threadIdx.x] = s;
 }
@@ -248,6 +264,8 @@ int main() {
     runpass<2>("pass: activation of registers MFMA never wrote", w, out, sink);
     runpass<3>("pass: accumulators in AGPRs (accvgpr_read)", w, out, sink);
     runpass<4>("pass: 1 value/step x 16, bias add + sin + cvt", w, out, sink);
+    runpass<8>("pass: 1 sin/step, cvt right behind its sine", w, out, sink);
+    runpass<9>("pass: 1 sin/step, cvt two steps behind (pipelined)", w, out, sink);
     runpass<5>("pass: 1 value/step, sine = 7-VALU polynomial", w, out, sink);
     runpass<6>("pass: 2 values/2 steps, polynomial in v_pk_*_f32", w, out, sink);
     runpass<7>("pass: 2 values/2 steps, polynomial in v_pk_*_f16", w, out, sink);
