@@ -281,6 +281,27 @@ def inr_path(dev, frames=5):
                                                                 f"({marked:.2e})"}}}
 
 
+def pipelined_frames(dev, params, grid, ext, live, frames=40, streams=3):
+    """A frame LOOP rather than a frame: the same config-3 frames dealt round-robin over `streams` HIP streams (each into its
+    own buffer), so that a frame's fill and drain overlap its neighbours'.  Wall clock over `frames` frames.  Reported beside
+    the headline, which stays one frame after the other on one stream (a single frame's latency is what it is)."""
+    import torch
+    import mrirt
+    ss = [torch.cuda.Stream(device=dev) for _ in range(streams)]
+    outs = [torch.empty((int(params["imageSize"][1]), int(params["imageSize"][0]), 4), dtype=torch.float32, device=dev) for _ in range(streams)]
+
+    def run(k):
+        for i in range(k):
+            mrirt.render_brats(params, [grid], out=outs[i % streams], ext=ext, stream=ss[i % streams])
+    torch.cuda.synchronize(); run(2 * streams); torch.cuda.synchronize()
+    t = time.perf_counter(); run(frames); torch.cuda.synchronize()
+    ms = (time.perf_counter() - t) / frames * 1e3
+    return {"what": f"{frames} frames of the same configuration dealt round-robin over {streams} HIP streams (frames in flight overlap; "
+                    "same kernel, same bits per frame)", "ms_per_frame": round(ms, 4), "value": round(live / (ms * 1e-3) / 1e6, 1),
+            "unit": "Msamples/s", "streams": streams,
+            "note": "throughput of a frame loop, not a frame's latency: the headline `value` above is one frame after the other on one stream"}
+
+
 def k1_reference_path(dev, frames=20):
     """BASELINE config 2 — the reference's own semantics, its primary parity target (inr/viewer/brats_rt.slang:117-165 as
     the viewer runs it): 256^3 x 4 modalities + seg overlay, 512 x 512 px, 256 steps/ray, perspective, no shading, STRICT
@@ -391,9 +412,10 @@ def scaling_model(dev, grid, n, march_steps, ext, tile, alpha, reps=10, skew_aut
     from mrirt import synth, tiles
     image = 2048
     p = synth.brats_scene(n, image, march_steps, channels=1, intensity_alpha=alpha)
-    share, worst_rank, mean_share, skews = {}, {}, {}, {}
+    share, worst_rank, mean_share, skews, flight = {}, {}, {}, {}, {}
+    ss = [torch.cuda.Stream(device=dev) for _ in range(3)]
     for world in (1, 2, 4, 8):
-        times = []
+        times, times3 = [], []
         skews[world] = tiles.balanced_skew(image, tile, world) if skew_auto else 0
         for r in range(world):
             e = tiles.shard_ext(ext, r, world, tile, skews[world])
@@ -406,7 +428,18 @@ def scaling_model(dev, grid, n, march_steps, ext, tile, alpha, reps=10, skew_aut
             e1.record()
             torch.cuda.synchronize()
             times.append(e0.elapsed_time(e1) / reps)
-            del out
+            # the same share as the N>1 frame loop runs it: three frames in flight, each on its own stream
+            outs = [out, torch.empty_like(out), torch.empty_like(out)]
+            for i in range(3):
+                mrirt.render_brats(p, [grid], out=outs[i], ext=e, stream=ss[i])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(3 * reps):
+                mrirt.render_brats(p, [grid], out=outs[i % 3], ext=e, stream=ss[i % 3])
+            torch.cuda.synchronize()
+            times3.append((time.perf_counter() - t0) / (3 * reps) * 1e3)
+            del out, outs
+        flight[world] = max(times3)
         share[world] = max(times)
         mean_share[world] = float(np.mean(times))
         worst_rank[world] = int(np.argmax(times))
@@ -434,6 +467,10 @@ def scaling_model(dev, grid, n, march_steps, ext, tile, alpha, reps=10, skew_aut
             "share_ms": {str(w): round(share[w], 4) for w in share}, "slowest_rank": {str(w): worst_rank[w] for w in worst_rank},
             "mean_rank_share_ms": {str(w): round(mean_share[w], 4) for w in mean_share},
             "pct_of_linear": {str(w): round(100.0 * share[1] / (w * share[w]), 1) for w in share},
+            "share_ms_three_frames_in_flight": {str(w): round(flight[w], 4) for w in flight},
+            "pct_of_linear_three_frames_in_flight": {str(w): round(100.0 * flight[1] / (w * flight[w]), 1) for w in flight},
+            "in_flight_note": "per-frame time of a rank's share when the frame loop keeps three frames in flight on three HIP streams (what bench.py --gpus N "
+                              "does): a share of one or two rounds of packets is mostly fill and drain, which consecutive frames hide for each other",
             "exchange_wire_ms_model": {str(w): round(wire[w], 4) for w in wire},
             "exchange_model": f"per peer: its compact tiles over one xGMI link at {link_gbs} GB/s x {eff} (assumed), peers in parallel; "
                               "asynchronous: overlaps the next frame's march (FrameExchange)",
@@ -487,34 +524,44 @@ def main():
     grid = mrirt.upload_grid(vol, (n, n, n), a.layout)            # resident in HBM (bricked on device)
     torch.cuda.synchronize()
 
+    DEPTH = 3        # frames in flight in the N>1 loop: each on its own HIP stream, so that frame k+1's march starts while frame k
+                     # drains (a launch of one or two rounds of packets is mostly fill and drain: profiles/r04_tile_share) and
+                     # frame k's gather overlaps both
     if grouped:
         skew = tiles.balanced_skew(image, a.tile, world) if a.tile_skew < 0 else a.tile_skew
         my_ext = tiles.shard_ext(ext, rank, world, a.tile, skew)
-        # double-buffered asynchronous exchange: frame k's gather to rank 0 overlaps frame k+1's march
-        ex = tiles.FrameExchange(image, image, a.tile, torch.float32, dev, depth=2, dst=0, skew=skew)
+        # asynchronous exchange, DEPTH slots: frame k's gather to rank 0 overlaps the marches of frames k+1, k+2
+        ex = tiles.FrameExchange(image, image, a.tile, torch.float32, dev, depth=DEPTH, dst=0, skew=skew)
         local = ex.local(0)
+        slot_streams = [torch.cuda.Stream(device=dev) for _ in range(DEPTH)]
     else:
         my_ext, ex = ext, None
         local = torch.empty((image, image, 4), dtype=torch.float32, device=dev)
+        slot_streams = None
 
     def run_frames(count, events=None):
         """`count` frames back to back; every frame is fully exchanged and de-tiled on rank 0
-        before this returns (the caller synchronises)."""
+        before this returns (the caller synchronises).  N = 1: one stream, one frame after the other (the headline number is
+        a single frame's time).  N > 1: frame s runs on slot s % DEPTH's stream — its wait for the slot's previous exchange, its
+        march and its gather are ordered on that stream; frames of different slots overlap."""
+        import contextlib
         for s in range(count):
-            slot = s % 2
-            if ex is not None and s >= 2:
-                ex.finish(slot)                       # frame s-2 used this slot: wait + de-tile it
-            buf = ex.local(slot) if ex is not None else local
-            if events is not None:
-                events[s][0].record()
-            mrirt.render_brats(params, [grid], out=buf, ext=my_ext)
-            if events is not None:
-                events[s][1].record()
-            if ex is not None:
-                ex.submit(slot)
+            slot = s % DEPTH
+            with (torch.cuda.stream(slot_streams[slot]) if ex is not None else contextlib.nullcontext()):
+                if ex is not None and s >= DEPTH:
+                    ex.finish(slot)                   # frame s-DEPTH used this slot: wait + de-tile it
+                buf = ex.local(slot) if ex is not None else local
+                if events is not None:
+                    events[s][0].record()
+                mrirt.render_brats(params, [grid], out=buf, ext=my_ext)
+                if events is not None:
+                    events[s][1].record()
+                if ex is not None:
+                    ex.submit(slot)
         if ex is not None:
-            for s in range(max(0, count - 2), count):
-                ex.finish(s % 2)
+            for s in range(max(0, count - DEPTH), count):
+                with torch.cuda.stream(slot_streams[s % DEPTH]):
+                    ex.finish(s % DEPTH)
 
     # untimed: sample accounting by the kernel's own counters
     _, st = mrirt.render_brats(params, [grid], out=local, ext=my_ext, stats=True)
@@ -541,11 +588,16 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    elapsed_local = elapsed
     if world > 1:
         e = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(e, op=dist.ReduceOp.MAX)
         elapsed = float(e[0])
     kernel_ms = float(np.mean([s.elapsed_time(t) for s, t in ev]))
+    if grouped:
+        # DEPTH frames are in flight: a frame's events bracket time it shares with its neighbours.  What a frame costs this rank is
+        # the loop's own pace.
+        kernel_ms = elapsed_local / a.steps * 1e3
     kernel_ms_all = [kernel_ms]
     if world > 1:
         km = torch.tensor([kernel_ms], dtype=torch.float64, device=dev)
@@ -569,7 +621,8 @@ def main():
         exchange = {"collective": "gather to rank 0 (RCCL, torch.distributed) + de-tiling kernel",
                     "bytes_to_root_per_frame": int((world - 1) * ex.max_local * a.tile * a.tile * 16),
                     "serial_ms_per_frame": round(ex_ms, 4),
-                    "note": "in the timed loop this step is asynchronous: frame k's gather overlaps frame k+1's march"}
+                    "note": f"in the timed loop this step is asynchronous: {DEPTH} frames in flight, each on its own stream — frame k's gather "
+                            "overlaps the marches of the next frames"}
 
     if rank == 0:
         value = live * a.steps / elapsed / 1e6
@@ -631,8 +684,12 @@ def main():
                          "bytes_per_sample": BYTES_PER_SAMPLE + (0 if a.no_shade else BYTES_PER_SHADED)},
         }
         if world > 1 or a.force_exchange:
-            out["per_rank"] = {"live_samples": [int(c[0]) for c in per_rank], "march_kernel_ms": [round(k, 4) for k in kernel_ms_all]}
+            out["per_rank"] = {"live_samples": [int(c[0]) for c in per_rank], "march_kernel_ms": [round(k, 4) for k in kernel_ms_all],
+                               "march_kernel_ms_is": f"this rank's wall time per frame of the timed loop ({DEPTH} frames in flight on {DEPTH} streams: "
+                                                     "per-launch durations overlap and are not reported)"}
             out["exchange"] = exchange
+        if world == 1 and not a.force_exchange:
+            out["pipelined"] = pipelined_frames(dev, params, grid, ext, live)
         if world == 1 and not a.no_k1:
             out["k1_reference_path"] = k1_reference_path(dev)
         if world == 1 and not a.no_inr:
