@@ -533,7 +533,7 @@ def main():
         # asynchronous exchange, DEPTH slots: frame k's gather to rank 0 overlaps the marches of frames k+1, k+2
         ex = tiles.FrameExchange(image, image, a.tile, torch.float32, dev, depth=DEPTH, dst=0, skew=skew)
         local = ex.local(0)
-        slot_streams = [torch.cuda.Stream(device=dev) for _ in range(DEPTH)]
+        slot_streams = [ex.stream(i) for i in range(DEPTH)]
     else:
         my_ext, ex = ext, None
         local = torch.empty((image, image, 4), dtype=torch.float32, device=dev)

@@ -129,6 +129,18 @@ class FrameExchange:
         if dst is not None and dist.is_initialized():
             self._gdst = dist.get_global_rank(group, dst) if group is not None else dst
         self._work = [None] * depth
+        self._streams = [None] * depth
+
+    def stream(self, i: int):
+        """Slot i's own HIP stream (device buffers only; None for host tensors): a frame loop that runs ``finish(i)`` → march into
+        ``local(i)`` → ``submit(i)`` under ``torch.cuda.stream(ex.stream(i))`` keeps ``depth`` frames in flight — frame k+1's march
+        starts while frame k's drains and frame k's exchange overlaps both (a rank's share of a frame is one or two rounds of
+        packets for the GPU, mostly fill and drain: DESIGN.md section 7)."""
+        if not self._send[i].is_cuda:
+            return None
+        if self._streams[i] is None:
+            self._streams[i] = torch.cuda.Stream(device=self._send[i].device)
+        return self._streams[i]
 
     def local(self, i: int) -> torch.Tensor:
         return self._send[i][:self.n_local]
