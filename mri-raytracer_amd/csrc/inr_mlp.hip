@@ -848,6 +848,25 @@ __global__ __launch_bounds__(256, 1) void inr_ws_kernel(const InrArgs a) {
         }
     };
 
+    // The same in two sweeps, for the places where no MFMA stream separates a sine from the convert that reads it (layer 0's passes,
+    // the last hidden layer's tail): sixteen independent transcendentals first, then the eight packed converts — a convert right
+    // behind its sines waits out the transcendental's latency, and with one wave per SIMD nothing else can issue meanwhile
+    // (s_memtime stamps: ~70 cycles per pass).
+    auto sin_one = [&](f32x16& ap, int i) {
+#ifndef MRIRT_WS_NOSIN
+        if constexpr (SIREN) ap[i] = __builtin_amdgcn_sinf(ap[i]);
+#endif
+    };
+    auto cvt_all = [&](f32x16& ap, bf16x8 (&Ho)[2]) {
+#pragma unroll
+        for (int i = 1; i < 16; i += 2) {
+            f32x2 x = { ap[i - 1], ap[i] };
+            if constexpr (!SIREN) x = __builtin_elementwise_max(x, (f32x2){ 0.0f, 0.0f });
+            Ho[i >> 3][(i & 7) - 1] = (__bf16)x.x;
+            Ho[i >> 3][i & 7] = (__bf16)x.y;
+        }
+    };
+
     // Head (linear, <= 4 classes): one out tile, so one wave per group — wave g reads group g's last hidden outputs
     // (parity NH & 1 ^ 1 ... written by all four waves before the barrier that precedes this) and the sixteen head
     // fragments from LDS, and stores logits / argmax.  np.argmax = first maximum.
@@ -912,6 +931,32 @@ __global__ __launch_bounds__(256, 1) void inr_ws_kernel(const InrArgs a) {
         // and run one after the other they cost a sixth of a round (profiles/r02_inr_ws_knockouts.txt).  Here pass
         // i's activation is sliced under pass i+1's MFMAs and two or three head MFMAs (waves 0..G-1: wave g takes
         // group g of the PREVIOUS round, sixteen k steps over the last hidden layer's outputs) per pass.
+        f32x16 carry;                                      // a phase's last accumulator, activated under the next phase's pass 0
+        // The head's epilogue (the previous round's logits -> stores, argmax, near-tie mark): ~70 VALU instructions, ~560 cycles on
+        // waves 0 .. G-1 at the end of the layer-0 phase (s_memtime stamps).  Moving it behind the barrier, under hidden layer 1's
+        // first LDS reads, moves the same 560 cycles there (measured: cycles per round level, wall time +0.3 %): it stays here.
+        f32x16 headAcc;
+        const bool headPending = prevRound >= 0 && w < G;
+        auto head_epilogue = [&]() {
+            if (!headPending) return;
+            mfma_drain(headAcc);
+            const int64_t pidx = (prevRound * G + w) * 32 + r;
+            if (h == 0 && pidx < nPts) {                       // classes 0..3 are rows 0..3: lane half 0, registers 0..3
+                const float v[4] = { headAcc[0], headAcc[1], headAcc[2], headAcc[3] };
+#ifndef MRIRT_WS_STAMPS
+                if (a.logits != nullptr)
+                    for (uint32_t c = 0; c < a.L.outDim; ++c) a.logits[pidx * a.L.outDim + c] = v[c];
+#endif
+                if (a.argmax != nullptr) {
+                    float best = -INFINITY, second = -INFINITY;
+                    uint32_t bestc = 0;
+#pragma unroll
+                    for (uint32_t c = 0; c < 4; ++c) top2_push(c < a.L.outDim ? v[c] : -INFINITY, c, best, second, bestc);   // strict: the first maximum
+                    const bool tie = a.tie != nullptr && !(best - second >= tieThr);     // near-tie mark (kFlagBit)
+                    a.argmax[pidx] = (int16_t)(bestc | (tie ? (uint32_t)kFlagBit : 0u));
+                }
+            }
+        };
 #if !defined(MRIRT_WS_NOL0)
         auto l0_head = [&](auto headC) {
             constexpr bool HEAD = decltype(headC)::value;
@@ -951,6 +996,7 @@ __global__ __launch_bounds__(256, 1) void inr_ws_kernel(const InrArgs a) {
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
                 const int g = i >> 1, j = i & 1;
+                WS_STAMP(15 + i);
                 if (j == 0 && g + 1 < G) { BinNext[0] = __builtin_bit_cast(bf16x8, bIn[((g + 1) * 2 + 0) * 64]); BinNext[1] = __builtin_bit_cast(bf16x8, bIn[((g + 1) * 2 + 1) * 64]); }
                 mfma_v(acc, wa[2 * j + 0], Bin[0]);
                 mfma_v(acc, wa[2 * j + 1], Bin[1]);
@@ -962,10 +1008,11 @@ __global__ __launch_bounds__(256, 1) void inr_ws_kernel(const InrArgs a) {
                     asm volatile("s_nop 15" : "+v"(accPrev));   // two MFMA issues + 16 states since accPrev's producer
 #pragma unroll
                     for (int v = 0; v < 16; ++v) {
-                        act_one(accPrev, Ho, v);
+                        sin_one(accPrev, v);
                         if (v == 3 || v == 9 || (v == 14 && i < 5)) { head_step(); __builtin_amdgcn_sched_barrier(0); }
-                        if (v == 7) wr_frag(pg, 1, pj, 0, Ho[0]);
                     }
+                    cvt_all(accPrev, Ho);
+                    wr_frag(pg, 1, pj, 0, Ho[0]);
                     wr_frag(pg, 1, pj, 1, Ho[1]);
                 } else {
                     head_step(); head_step(); head_step();
@@ -974,35 +1021,14 @@ __global__ __launch_bounds__(256, 1) void inr_ws_kernel(const InrArgs a) {
                 accPrev = acc;
                 if (i + 1 < NP) acc = accNext;
             }
-            // the last pass's activation, under whatever is left of the head
+            // the last pass's activation is carried into hidden layer 1's pass 0 (see `carry` below); what is left of the head:
+            WS_STAMP(21);
             head_step();
-            mfma_drain(accPrev);
-#pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                act_one(accPrev, Ho, v);
-                if (v == 5 || v == 11) head_step();
-            }
-            wr_frag(G - 1, 1, 1, 0, Ho[0]);
-            wr_frag(G - 1, 1, 1, 1, Ho[1]);
+            carry = accPrev;
             if constexpr (HEAD) {
                 while (hk < KS) head_step();                   // (none left with G = 3: 3 + 3*4 ... counted at compile time)
-                mfma_drain(hacc);
-                const int64_t pidx = (prevRound * G + w) * 32 + r;
-                if (h == 0 && pidx < nPts) {                   // classes 0..3 are rows 0..3: lane half 0, registers 0..3
-                    const float v[4] = { hacc[0], hacc[1], hacc[2], hacc[3] };
-#ifndef MRIRT_WS_STAMPS
-                    if (a.logits != nullptr)
-                        for (uint32_t c = 0; c < a.L.outDim; ++c) a.logits[pidx * a.L.outDim + c] = v[c];
-#endif
-                    if (a.argmax != nullptr) {
-                        float best = -INFINITY, second = -INFINITY;
-                        uint32_t bestc = 0;
-#pragma unroll
-                        for (uint32_t c = 0; c < 4; ++c) top2_push(c < a.L.outDim ? v[c] : -INFINITY, c, best, second, bestc);   // strict: the first maximum
-                        const bool tie = a.tie != nullptr && !(best - second >= tieThr);     // near-tie mark (kFlagBit)
-                        a.argmax[pidx] = (int16_t)(bestc | (tie ? (uint32_t)kFlagBit : 0u));
-                    }
-                }
+                headAcc = hacc;
+                head_epilogue();
             }
         };
 #ifdef MRIRT_WS_NOHEAD
@@ -1015,14 +1041,22 @@ __global__ __launch_bounds__(256, 1) void inr_ws_kernel(const InrArgs a) {
         WS_SYNC();
         WS_STAMP(2);
         // ---- hidden layers: layer l reads parity (l & 1), writes the other; the last one feeds the head ---------
+        // The last pass of a layer has no MFMAs of its own layer left to hide its activation under: as a tail after the loop it
+        // cost 476 cycles per layer (s_memtime stamps, profiles/r04_inr_ws/).  Layers 0, 1 and 2 therefore hand their last
+        // accumulator to the NEXT layer (`carry`), whose pass 0 — which had nothing to cover — activates it and writes it into the
+        // buffer that layer reads (group G - 1, tile 1).  Group G - 1 is first read by the B-fragment ring's look-ahead, RD steps before
+        // pass 2 (G - 1), i.e. late in pass 2 (G - 1) - 1: one more barrier at the START of that pass orders the carried writes
+        // (made three passes earlier); groups 0 .. G - 2 were complete at the layer-boundary barrier as before.
         auto hidden = [&](auto lC) {
             constexpr int l = decltype(lC)::value;            // 1 .. NH
             constexpr int par = l & 1;
             constexpr int NP = 2 * G;                          // tile passes: (group g, tile j) = (i >> 1, i & 1)
+            constexpr bool CARRY_IN = true, CARRY_OUT = l < NH;      // layer 1 takes layer 0's last pass
             bf16x8 ring[RD];
 #pragma unroll
             for (int d = 0; d < RD; ++d) ring[d] = rd_frag(0, par, d);
             f32x16 accPrev;
+            if constexpr (CARRY_IN) accPrev = carry;
             bf16x8 Ho[2];                                      // packed outputs of the previous pass
             bf16x8 w3[4];                                      // layer 3: the LDS-held A fragments of tile 1, k steps 12..15
             f32x16 acc = bias_tile(l, 0);
@@ -1031,6 +1065,8 @@ __global__ __launch_bounds__(256, 1) void inr_ws_kernel(const InrArgs a) {
                 const int j = i & 1;
                 f32x16 accNext;
                 if constexpr (l == 1) WS_STAMP(8 + i);
+                static_assert(RD <= KS, "the ring's look-ahead reaches group G - 1 no earlier than pass 2 (G - 1) - 1");
+                if (CARRY_IN && i == 2 * (G - 1) - 1) WS_SYNC();   // the previous layer's carried unit is in LDS on every wave
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     const int q = i * KS + ks;                 // position in the phase's B-fragment stream
@@ -1039,18 +1075,19 @@ __global__ __launch_bounds__(256, 1) void inr_ws_kernel(const InrArgs a) {
                     else mfma_v(acc, Wh[l - 1][j][ks], ring[q % RD]);                               // layer 3: arch VGPRs
                     if (q + RD < NP * KS) ring[q % RD] = rd_frag((q + RD) / KS >> 1, par, (q + RD) % KS);
                     if constexpr (l == NH) { if (j == 1 && ks >= KS - 7 && ks < KS - 3) w3[ks - (KS - 7)] = __builtin_bit_cast(bf16x8, bWt[kW0Q + kWoQ + (ks - (KS - 7)) * 64]); }
-                    if (i > 0) {
-                        // the previous pass's accumulator, ONE value per step (two in steps 2 and 3): a v_sin next to an MFMA costs
-                        // ~16 issue cycles, two of them overflow the 24 an MFMA leaves (tools/micro/mfma_pace.hip: 709 cycles per
-                        // pass against 549 without activation).  The compiler does not know the asm statements are MFMAs, so
-                        // the XDL-write -> VALU-read wait is kept by hand: two MFMA issues, two LDS issues and 4 idle states.
-                        const int pg = (i - 1) >> 1, pj = (i - 1) & 1;
+                    if (i > 0 || CARRY_IN) {
+                        // the previous pass's accumulator (pass 0: the previous LAYER's last one), ONE value per step (two in steps 2
+                        // and 3): a v_sin next to an MFMA costs ~16 issue cycles, two of them overflow the 24 an MFMA leaves
+                        // (tools/micro/mfma_pace.hip).  The compiler does not know the asm statements are MFMAs, so the XDL-write ->
+                        // VALU-read wait is kept by hand: two MFMA issues, two LDS issues and 4 idle states.
+                        // Where it goes: this layer's output buffer (par ^ 1) — the carried unit into the buffer this layer READS (par).
+                        const int pg = i > 0 ? (i - 1) >> 1 : G - 1, pj = i > 0 ? (i - 1) & 1 : 1, wpar = i > 0 ? (par ^ 1) : par;
                         if (ks == 1) asm volatile("s_nop 3" : "+v"(accPrev));
                         if (ks == 2) { act_one(accPrev, Ho, 0); act_one(accPrev, Ho, 1); }
                         if (ks == 3) { act_one(accPrev, Ho, 2); act_one(accPrev, Ho, 3); }
                         if (ks >= 4) act_one(accPrev, Ho, ks);
-                        if (ks == 8) wr_frag(pg, par ^ 1, pj, 0, Ho[0]);
-                        if (ks == 15) wr_frag(pg, par ^ 1, pj, 1, Ho[1]);
+                        if (ks == 8) wr_frag(pg, wpar, pj, 0, Ho[0]);
+                        if (ks == 15) wr_frag(pg, wpar, pj, 1, Ho[1]);
                     }
                     if (ks == 11 && i + 1 < NP) accNext = bias_tile(l, (i + 1) & 1);
                     __builtin_amdgcn_sched_barrier(0);
@@ -1058,13 +1095,18 @@ __global__ __launch_bounds__(256, 1) void inr_ws_kernel(const InrArgs a) {
                 accPrev = acc;
                 if (i + 1 < NP) acc = accNext;
             }
-            // the phase's last pass
             if constexpr (l == 1) WS_STAMP(8 + NP);
-            mfma_drain(accPrev);
+            if constexpr (CARRY_OUT) {
+                carry = accPrev;                               // activated under the next layer's pass 0
+            } else {
+                // the last hidden layer's last pass: the head reads it in the next phase
+                mfma_drain(accPrev);
 #pragma unroll
-            for (int v = 0; v < 16; ++v) act_one(accPrev, Ho, v);
-            wr_frag(G - 1, par ^ 1, 1, 0, Ho[0]);
-            wr_frag(G - 1, par ^ 1, 1, 1, Ho[1]);
+                for (int v = 0; v < 16; ++v) sin_one(accPrev, v);
+                cvt_all(accPrev, Ho);
+                wr_frag(G - 1, par ^ 1, 1, 0, Ho[0]);
+                wr_frag(G - 1, par ^ 1, 1, 1, Ho[1]);
+            }
         };
         hidden(IC<1>{});
         WS_STAMP(3);

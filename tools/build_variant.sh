@@ -10,7 +10,7 @@ OUT=$REPO/build_exp
 mkdir -p $OUT/obj
 FLAGS="-O3 --offload-arch=gfx950 -ffp-contract=off -fPIC -std=c++17 -Wall -I$REPO/include"
 OBJS=""
-for f in brats_march brats_slab volume_march grid_ops inr_mlp; do
+for f in brats_march brats_slab brats_ring volume_march grid_ops inr_mlp; do
   if [ "$f.hip" == "$SRC" ]; then
     /opt/rocm/bin/hipcc $FLAGS "$@" -c $CS/$f.hip -o $OUT/obj/${f}_$NAME.o
     OBJS="$OBJS $OUT/obj/${f}_$NAME.o"
@@ -21,5 +21,6 @@ for f in brats_march brats_slab volume_march grid_ops inr_mlp; do
     OBJS="$OBJS $OUT/obj/$f.o"
   fi
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -o $OUT/libmrirt_$NAME.so
+if [ ! -f $OUT/obj/abort_trace.o ] || [ $CS/abort_trace.cpp -nt $OUT/obj/abort_trace.o ]; then /opt/rocm/bin/hipcc $FLAGS -c $CS/abort_trace.cpp -o $OUT/obj/abort_trace.o; fi
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS $OUT/obj/abort_trace.o -o $OUT/libmrirt_$NAME.so
 echo built $OUT/libmrirt_$NAME.so

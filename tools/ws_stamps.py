@@ -9,7 +9,7 @@ rng = np.random.default_rng(0)
 dims = [7, 256, 256, 256, 256, 4]
 params = [{"W": (rng.uniform(-1, 1, (dims[i], dims[i + 1])) * math.sqrt(6.0 / dims[i]) / (30.0 if i == 0 else 1.0)).astype(np.float32),
            "b": rng.uniform(-0.05, 0.05, dims[i + 1]).astype(np.float32)} for i in range(5)]
-net = inr.pack_mlp(params, inr.KIND_SIREN, 0, 4)
+net = inr.with_flags(inr.pack_mlp(params, inr.KIND_SIREN, 0, 4), no_refine=True)      # the second pass would overwrite the stamps
 n = 256 * 96 * 40
 coords = torch.rand((n, 3), device="cuda") * 2 - 1
 feats = torch.randn((n, 4), device="cuda")
@@ -26,6 +26,9 @@ if True:
   for wv in (0, 3):
     print("wave", wv, "hidden1 passes:", "prologue", int(np.median(st[:, wv, 8] - st[:, wv, 2])),
           [int(np.median(st[:, wv, 9 + k] - st[:, wv, 8 + k])) for k in range(6)], "tail", int(np.median(st[:, wv, 3] - st[:, wv, 14])))
+for wv in (0, 3):
+    print("wave", wv, "L0+head passes:", "prologue", int(np.median(st[:, wv, 15] - st[:, wv, 0])),
+          [int(np.median(st[:, wv, 16 + k] - st[:, wv, 15 + k])) for k in range(6)], "tail (last activation, head end, stores)", int(np.median(st[:, wv, 1] - st[:, wv, 21])))
 if False:
   for wv in range(4):
     print("v2 wave", wv, "L0+head", int(np.median(st[:, wv, 1] - st[:, wv, 0])), "H1", int(np.median(st[:, wv, 2] - st[:, wv, 1])),
