@@ -490,3 +490,41 @@ def test_c2_full_size_against_the_oracle(env):
         assert np.array_equal(got.cpu().numpy(), ref), layout
         assert st["live_samples"] == aux["live_samples"]
         del g, gl
+
+
+def test_frames_in_flight_on_slot_streams(env):
+    """The N > 1 frame loop of bench.py: DEPTH frames in flight, slot s of FrameExchange on its own HIP stream (wait for the slot's
+    previous exchange -> march into the slot's compact buffer -> submit).  Single process (the exchange is a device copy), three
+    cameras cycling through three slots for nine frames: every de-tiled frame must be the whole-frame render of ITS camera — a
+    slot reused too early, or a march ordered on the wrong stream, shows up as another camera's pixels."""
+    torch, mrirt, synth = env["torch"], env["mrirt"], env["synth"]
+    from mrirt import tiles
+    n, image, tile, depth = 96, 320, 64, 3
+    vol = synth.synth_volume(n)
+    g = mrirt.upload_grid(vol, (n, n, n), "vga")
+    ext = dict(synth.SHADE_EXT, layout="vga")
+    cams = []
+    for k in range(3):
+        p = synth.brats_scene(n, image, 160, channels=1, intensity_alpha=8.0)
+        cam = mrirt.OrbitalCamera(initial_radius=3.0, initial_phi=np.radians(60 + 25 * k), initial_theta=np.radians(20 - 30 * k))
+        p["eye"], p["U"], p["V"], p["W"] = cam.get_basis()
+        cams.append((p, mrirt.render_brats(p, [g], ext=ext)))
+    skew = tiles.balanced_skew(image, tile, 1)
+    ex = tiles.FrameExchange(image, image, tile, torch.float32, "cuda", depth=depth, dst=0, skew=skew)
+    my_ext = tiles.shard_ext(ext, 0, 1, tile, skew)
+    got = []
+    torch.cuda.synchronize()
+    for s in range(9):
+        slot = s % depth
+        with torch.cuda.stream(ex.stream(slot)):
+            if s >= depth:
+                got.append((s - depth, ex.finish(slot).clone()))
+            mrirt.render_brats(cams[s % 3][0], [g], out=ex.local(slot), ext=my_ext)
+            ex.submit(slot)
+    for s in range(9 - depth, 9):
+        with torch.cuda.stream(ex.stream(s % depth)):
+            got.append((s, ex.finish(s % depth).clone()))
+    torch.cuda.synchronize()
+    assert len(got) == 9
+    for s, frame in got:
+        assert torch.equal(frame, cams[s % 3][1]), s
