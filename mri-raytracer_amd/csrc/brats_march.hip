@@ -140,9 +140,10 @@ struct MapWindow {
             // trailing edge per axis, by the first live lane's direction of travel (the packet's rays are near-parallel)
             const int first = __ffsll((long long)__ballot(alive)) - 1;
             const bool px = __shfl(rd[0], first) >= 0.0f, py = __shfl(rd[1], first) >= 0.0f, pz = __shfl(rd[2], first) >= 0.0f;
-            ox = window_origin(px, wave_min8(alive ? cx : 255u), wave_max8(alive ? cx : 0u));
-            oy = window_origin(py, wave_min8(alive ? cy : 255u), wave_max8(alive ? cy : 0u));
-            oz = window_origin(pz, wave_min8(alive ? cz : 255u), wave_max8(alive ? cz : 0u));
+            // (one reduction per axis, the one its direction needs: eight ballots each — px / py / pz are wave-uniform)
+            ox = px ? window_origin(true, wave_min8(alive ? cx : 255u), 0u) : window_origin(false, 0u, wave_max8(alive ? cx : 0u));
+            oy = py ? window_origin(true, wave_min8(alive ? cy : 255u), 0u) : window_origin(false, 0u, wave_max8(alive ? cy : 0u));
+            oz = pz ? window_origin(true, wave_min8(alive ? cz : 255u), 0u) : window_origin(false, 0u, wave_max8(alive ? cz : 0u));
             uint32_t v = a.skipDist[window_fetch_index(ox, oy, oz, lane, a.mX, a.mY, a.mZ, a.mXY)];
             asm volatile("" : "+v"(v));                             // the wait for this load belongs inside the branch
             bytes = v;

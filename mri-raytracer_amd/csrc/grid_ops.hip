@@ -367,7 +367,9 @@ extern "C" int mrirt_detile(const void* gathered, void* frame, uint32_t width, u
     if (width == 0 || height == 0) return MRIRT_ERR_DIMS;
     if (tileSize == 0 || world == 0 || pitch_px < (int64_t)width) return MRIRT_ERR_ARG;
     if (outFormat > MRIRT_OUT_RGBA16F) return MRIRT_ERR_LAYOUT;
+    if (width > (1u << 20) || height > (1u << 20) || tileSize < 16) return MRIRT_ERR_DIMS;
     const uint32_t tilesX = (width + tileSize - 1) / tileSize;
+    tileSkew %= tilesX;
     const uint32_t maxLocal = (uint32_t)mrirt_tiles_for_rank(width, height, tileSize, 0, world);
     const dim3 grid((width + 15) / 16, (height + 15) / 16), block(256);
     hipStream_t s = static_cast<hipStream_t>(stream);

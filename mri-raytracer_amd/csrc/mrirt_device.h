@@ -333,14 +333,15 @@ struct PixelMap {
 // Grid is chunk*8 workgroups.  Returns 0: this lane has no pixel (whole workgroups past
 // numBlocks, or whole-frame lanes beyond the image edge); 1: march pixel (px,py) and store at
 // outIndex; 2: (tile mode) a compact-buffer slot outside the image: store background only.
-// tile sharding: where the dealt tile t sits in the image, and which dealt index a tile position has (inverse)
+// tile sharding: where the dealt tile t sits in the image, and which dealt index a tile position has (inverse).
+// `skew` is the host's MrirtRenderExt::tileSkew reduced modulo tilesX (fill_pixel_map, mrirt_detile) and tile rows number < 2^16
+// (images < 2^20 px, tiles >= 16 px), so skew * ty stays in 32 bits.
 MRIRT_HD void tile_position(uint32_t t, uint32_t tilesX, uint32_t skew, uint32_t& tx, uint32_t& ty) {
     ty = t / tilesX;
-    tx = (t % tilesX + (uint32_t)(((uint64_t)skew * ty) % tilesX)) % tilesX;
+    tx = (t % tilesX + (skew * ty) % tilesX) % tilesX;
 }
 MRIRT_HD uint32_t tile_dealt_index(uint32_t tx, uint32_t ty, uint32_t tilesX, uint32_t skew) {
-    const uint32_t rot = (uint32_t)(((uint64_t)skew * ty) % tilesX);
-    return ty * tilesX + (tx + tilesX - rot) % tilesX;
+    return ty * tilesX + (tx + tilesX - (skew * ty) % tilesX) % tilesX;
 }
 
 MRIRT_HD int map_pixel_at(const PixelMap& m, uint32_t b, uint32_t tid, uint32_t& px, uint32_t& py, int64_t& outIndex) {

@@ -83,7 +83,7 @@ inline int fill_pixel_map(PixelMap& m, uint32_t width, uint32_t height, int64_t 
     m.tileSize = ext ? ext->tileSize : 0u;
     m.tileRank = ext ? ext->tileRank : 0u;
     m.tileWorld = ext ? ext->tileWorld : 0u;
-    m.tileSkew = ext ? ext->tileSkew : 0u;
+    m.tileSkew = 0u;
     m.laneOrder = laneOrder;
     m.blockPx = blockPx;
     if (m.tileSize == 0) {
@@ -93,7 +93,9 @@ inline int fill_pixel_map(PixelMap& m, uint32_t width, uint32_t height, int64_t 
         m.numBlocks = m.blocksX * ((height + blockPx - 1) / blockPx);
     } else {
         if (m.tileSize % kBlockPx != 0 || m.tileWorld == 0 || m.tileRank >= m.tileWorld) return MRIRT_ERR_ARG;
+        if (width > (1u << 20) || height > (1u << 20)) return MRIRT_ERR_DIMS;       // (tile rows < 2^16: tile_position's 32-bit products)
         m.tilesX = (width + m.tileSize - 1) / m.tileSize;
+        m.tileSkew = (ext ? ext->tileSkew : 0u) % m.tilesX;
         int64_t local = mrirt_tiles_for_rank(width, height, m.tileSize, m.tileRank, m.tileWorld);
         uint32_t bpr = m.tileSize / blockPx;
         m.blocksX = 0;

@@ -390,7 +390,8 @@ int main() {
                 }
         // the skewed deal is a permutation of the tile grid, and tile_dealt_index inverts tile_position (the de-tiling kernel's side)
         for (uint32_t tilesX : { 1u, 3u, 32u, 33u })
-            for (uint32_t skew : { 0u, 1u, 7u, 31u, 4000000000u }) {
+            for (uint32_t skewAsked : { 0u, 1u, 7u, 31u, 4000000000u }) {
+                const uint32_t skew = skewAsked % tilesX;                       // (what fill_pixel_map / mrirt_detile hand the kernels)
                 std::vector<uint8_t> hit(tilesX * 5u, 0);
                 for (uint32_t t = 0; t < tilesX * 5u; ++t) {
                     uint32_t tx, ty;
