@@ -80,6 +80,8 @@ def parse():
     ap.add_argument("--no-inr", action="store_true", help="skip the INR (MFMA) side measurement")
     ap.add_argument("--no-k1", action="store_true", help="skip the config-2 (reference K1 semantics) side measurement")
     ap.add_argument("--no-scaling-model", action="store_true", help="N=1: skip the one-GPU emulation of the 1/2/4/8-rank tile shares")
+    ap.add_argument("--no-pipelined", action="store_true", help="N=1: skip the frames-in-flight side measurement (profiling runs: overlapped "
+                                                                 "launches of the same kernel would blur its per-launch statistics)")
     ap.add_argument("--force-exchange", action="store_true",
                     help="N=1 only: still create the RCCL group (world size 1), render compact tiles and run the "
                          "asynchronous gather + de-tiling path — a single-GPU rehearsal of the N>1 code")
@@ -688,7 +690,7 @@ def main():
                                "march_kernel_ms_is": f"this rank's wall time per frame of the timed loop ({DEPTH} frames in flight on {DEPTH} streams: "
                                                      "per-launch durations overlap and are not reported)"}
             out["exchange"] = exchange
-        if world == 1 and not a.force_exchange:
+        if world == 1 and not a.force_exchange and not a.no_pipelined:
             out["pipelined"] = pipelined_frames(dev, params, grid, ext, live)
         if world == 1 and not a.no_k1:
             out["k1_reference_path"] = k1_reference_path(dev)

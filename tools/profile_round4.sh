@@ -7,12 +7,12 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$REPO/gpurun_out/r04
 rm -rf $O; mkdir -p $O
 cd $REPO
-bash tools/profile_r04.sh c3_vga "C3:512:1024:512:vga:strict:shade" "pipe_kernel<true, 4" bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-inr --no-k1 --no-scaling-model > $O/profile_c3.log 2>&1; echo "c3 pmc done"
+bash tools/profile_r04.sh c3_vga "C3:512:1024:512:vga:strict:shade" "pipe_kernel<true, 4" bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-inr --no-k1 --no-scaling-model --no-pipelined > $O/profile_c3.log 2>&1; echo "c3 pmc done"
 bash tools/profile_r04.sh c2_quad "C2:256:512:256:quad:strict:4ch+seg" "pipe_kernel<true, 3, false, 4" tools/c2_run.py 10 > $O/profile_c2.log 2>&1; echo "c2 pmc done"
 # the C3 kernel on a 256^3 volume (1.5 GiB of VGA voxels: Infinity-Cache resident), at the same ray spacing in voxels
 # (512^2 px, 256 steps) and at the full image (1024^2 px, 512 steps)
-bash tools/profile_r04.sh c3_256_512px "C3:256:512:256:vga:strict:shade" "pipe_kernel<true, 4" bench.py --volume 256 --image 512 --march-steps 256 --steps 10 --warmup 2 --no-cpu-baseline --no-inr --no-k1 --no-scaling-model > $O/profile_c3_256a.log 2>&1; echo "c3 256 (512px) pmc done"
-bash tools/profile_r04.sh c3_256_1024px "C3:256:1024:512:vga:strict:shade" "pipe_kernel<true, 4" bench.py --volume 256 --steps 10 --warmup 2 --no-cpu-baseline --no-inr --no-k1 --no-scaling-model > $O/profile_c3_256b.log 2>&1; echo "c3 256 (1024px) pmc done"
+bash tools/profile_r04.sh c3_256_512px "C3:256:512:256:vga:strict:shade" "pipe_kernel<true, 4" bench.py --volume 256 --image 512 --march-steps 256 --steps 10 --warmup 2 --no-cpu-baseline --no-inr --no-k1 --no-scaling-model --no-pipelined > $O/profile_c3_256a.log 2>&1; echo "c3 256 (512px) pmc done"
+bash tools/profile_r04.sh c3_256_1024px "C3:256:1024:512:vga:strict:shade" "pipe_kernel<true, 4" bench.py --volume 256 --steps 10 --warmup 2 --no-cpu-baseline --no-inr --no-k1 --no-scaling-model --no-pipelined > $O/profile_c3_256b.log 2>&1; echo "c3 256 (1024px) pmc done"
 python3 - <<'PY'
 import json, glob, os
 root = os.environ.get("GRAFT_REPO_ROOT", os.getcwd())
