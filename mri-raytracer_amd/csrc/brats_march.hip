@@ -367,7 +367,10 @@ __device__ __forceinline__ void march_skip(const K1Args& a, const WaveGrid<LAYOU
     }
 }
 
-template <bool STRICT, int LAYOUT, bool SHADE, int NCH, bool GAMMA1, bool LABELS, bool SKIP, bool CELLS = false>
+// TAG: the same code under a second symbol (kernelVariant bit 15).  bench.py's side measurements — tile shares, frames in flight —
+// launch the kernel it benches at other sizes and overlapped; under the tag a profiler's per-kernel statistics keep them apart
+// from the benched launches.  Instantiated for the benched configuration only (launch_pipe).
+template <bool STRICT, int LAYOUT, bool SHADE, int NCH, bool GAMMA1, bool LABELS, bool SKIP, bool CELLS = false, bool TAG = false>
 __global__ __launch_bounds__(256, (LABELS || SKIP) ? 3 : 4) void brats_march_pipe_kernel(const K1Args a) {
     __shared__ float4 lutShared[LABELS ? 16 : 1];
     const float4* lutS = nullptr;
@@ -626,6 +629,13 @@ static int launch_pipe(const K1Args& a, hipStream_t s) {
     }
     if (STRICT && a.gamma == 1.0f && !overlays) {
         if constexpr (kHasSkip) { if (skip) { hipLaunchKernelGGL((brats_march_pipe_kernel<STRICT, LAYOUT, SHADE, NCH, STRICT, !STRICT, true>), grid, block, 0, s, a); MRIRT_HIP(hipGetLastError()); return MRIRT_OK; } }
+        if constexpr (STRICT && LAYOUT == 4 && SHADE && NCH == 1) {
+            if (a.debugFlags & 256u) {                                  // kernelVariant bit 15: the tagged twin
+                hipLaunchKernelGGL((brats_march_pipe_kernel<STRICT, LAYOUT, SHADE, NCH, STRICT, !STRICT, false, false, true>), grid, block, 0, s, a);
+                MRIRT_HIP(hipGetLastError());
+                return MRIRT_OK;
+            }
+        }
         hipLaunchKernelGGL((brats_march_pipe_kernel<STRICT, LAYOUT, SHADE, NCH, STRICT, !STRICT, false>), grid, block, 0, s, a);
     } else if (STRICT && a.gamma == 1.0f) {
         if constexpr (kHasSkip) { if (skip) { hipLaunchKernelGGL((brats_march_pipe_kernel<STRICT, LAYOUT, SHADE, NCH, STRICT, true, true>), grid, block, 0, s, a); MRIRT_HIP(hipGetLastError()); return MRIRT_OK; } }
@@ -1087,6 +1097,7 @@ static int prepare(const MrirtBratsParams* p, const MrirtRenderExt* ext, const v
     a.expSmall = (fabsf(p->intensityAlpha * p->stepSize) <= 0.125f) ? 1u : 0u;   // val is in [0, 1]
     a.out = nullptr; a.stats = nullptr;
     a.debugFlags = (variant >> 7) & 15u;
+    if (variant & 32768u) a.debugFlags |= 256u;                        // the tagged twin of the benched kernel (launch_pipe)
     if (variant & 4096u) a.debugFlags |= 32u;                          // ring kernel: three planes instead of four
     cfg.layout = layout; cfg.math = math;
     cfg.shade = ext && ext->shadeMode != 0;
@@ -1183,6 +1194,7 @@ using namespace mrirt;
 //                                                             kernels: the samples they did NOT fetch (flagged or leapt)
 //   bit 8: skipping one step at a time (no leaps); in the slab kernel: count ring misses
 //   bit 9: every band of an XCD starts at x = 0 (no per-band shift of the workgroup order: PixelMap::bandShift)
+//   bit 15: the tagged twin of the benched kernel (same code, another symbol: bench.py's side measurements)
 extern "C" int mrirt_render_brats_ex(const MrirtBratsParams* p, const MrirtRenderExt* ext,
                                      const void* const vol[4], const void* labels, const void* preds,
                                      void* out_rgba, int64_t pitch_px, uint64_t* stats_dev, void* stream) {
