@@ -27,7 +27,7 @@ so in ``basis``.  SURVEY 8(d)'s algorithmic rate (cache-served taps, can exceed 
 ``algorithmic_GBs``; ``on_chip`` carries the two on-chip roofs that actually bind this kernel.
 
 Launching.  ``python bench.py --gpus N`` with N > 1 and no WORLD_SIZE in the environment starts the N ranks
-itself: the parent makes no HIP call (it only counts devices), runs ``python -m torch.distributed.run
+itself: the parent only counts devices, runs ``python -m torch.distributed.run
 --nproc-per-node N`` on this file as a CHILD process (never an exec), relays rank 0's JSON line and exits with
 the children's status; with fewer than N devices visible it exits non-zero instead of printing an N=1 line.  Under
 torch.distributed.run (WORLD_SIZE set, as the driver launches it) each process is one rank.
@@ -95,8 +95,9 @@ def parse():
 
 def launch_ranks(a):
     """``--gpus N`` (N > 1) outside torch.distributed.run: start the N ranks as children of this process.
-    Nothing here touches the GPU (torch.cuda.device_count() does not initialise HIP), and the ranks are a child
-    process, not an exec of this one."""
+    The parent only COUNTS devices (``torch.cuda.device_count()`` — on ROCm that may go through ``hipGetDeviceCount``, which does
+    not create a context or touch a queue) and never renders; the ranks are a CHILD process (``subprocess.run``), not an exec of
+    this one, so whatever the count initialised in the parent is irrelevant to them."""
     if not a.dry_run:
         import torch
         have = torch.cuda.device_count()
