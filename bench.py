@@ -57,6 +57,7 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0   # same guide: dense bf16 (the 5 PF headline inc
 BYTES_PER_SAMPLE = 32         # 8 taps x 4 B, one fp32 channel          
 BYTES_PER_SHADED = 192        # + 6 x 8 taps x 4 B central differences  
 BYTES_PER_PIXEL = 16          # fp32 RGBA framebuffer store
+DEPTH = 3                     # frames in flight in the N>1 loop (exchange slots; on the GPU each slot has its own HIP stream)
 
 
 def parse():
@@ -135,21 +136,21 @@ def dry_run(a, world, rank):
         return px / 16.0 + float(t)
 
     skew = tiles.balanced_skew(image, a.tile, world)
-    ex = tiles.FrameExchange(image, image, a.tile, torch.float32, "cpu", depth=2, dst=0, skew=skew)
+    ex = tiles.FrameExchange(image, image, a.tile, torch.float32, "cpu", depth=DEPTH, dst=0, skew=skew)
     owned = list(range(rank, n_tiles, world))
     assert len(owned) == ex.n_local
     t0 = time.perf_counter()
     frame = None
     for s in range(a.warmup + a.steps):
-        slot = s % 2
-        if s >= 2:
+        slot = s % DEPTH
+        if s >= DEPTH:
             frame = ex.finish(slot)
         buf = ex.local(slot)
         for lt, t in enumerate(owned):
             buf[lt] = tile_pattern(t)
         ex.submit(slot)
-    for s in range(max(0, a.warmup + a.steps - 2), a.warmup + a.steps):
-        frame = ex.finish(s % 2)
+    for s in range(max(0, a.warmup + a.steps - DEPTH), a.warmup + a.steps):
+        frame = ex.finish(s % DEPTH)
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -539,9 +540,8 @@ def main():
     grid = mrirt.upload_grid(vol, (n, n, n), a.layout)            # resident in HBM (bricked on device)
     torch.cuda.synchronize()
 
-    DEPTH = 3        # frames in flight in the N>1 loop: each on its own HIP stream, so that frame k+1's march starts while frame k
-                     # drains (a launch of one or two rounds of packets is mostly fill and drain: profiles/r04_tile_share) and
-                     # frame k's gather overlaps both
+    # DEPTH frames in flight in the N>1 loop: each on its own HIP stream, so that frame k+1's march starts while frame k drains (a
+    # launch of one or two rounds of packets is mostly fill and drain: profiles/r04_tile_share) and frame k's gather overlaps both
     if grouped:
         skew = tiles.balanced_skew(image, a.tile, world) if a.tile_skew < 0 else a.tile_skew
         my_ext = tiles.shard_ext(ext, rank, world, a.tile, skew)
