@@ -45,18 +45,19 @@ def _worker(rank, world, port, w, h, tile, all_ranks, q):
             ok = frame is not None and torch.equal(frame, torch.from_numpy(full))
         else:
             ok = frame is None
-        # the frame-loop form: double-buffered asynchronous exchange, 5 frames in flight order
-        ex = tiles.FrameExchange(w, h, tile, torch.float32, "cpu", depth=2, dst=0, skew=skew)
-        assert ex.n_local == n_local
+        # the frame-loop form, as bench.py --gpus N runs it: an asynchronous exchange with three slots, 8 frames in flight order
+        D = 3
+        ex = tiles.FrameExchange(w, h, tile, torch.float32, "cpu", depth=D, dst=0, skew=skew)
+        assert ex.n_local == n_local and ex.stream(0) is None       # (host tensors have no slot streams)
         got = []
-        for f in range(5):
-            slot = f % 2
-            if f >= 2:
+        for f in range(8):
+            slot = f % D
+            if f >= D:
                 got.append(ex.finish(slot))
             ex.local(slot).copy_(local + float(f))
             ex.submit(slot)
-        for f in range(3, 5):
-            got.append(ex.finish(f % 2))
+        for f in range(8 - D, 8):
+            got.append(ex.finish(f % D))
         for f, fr in enumerate(got):
             ok = ok and ((fr is None) if rank != 0 else torch.equal(fr, torch.from_numpy(full) + float(f)))
         q.put((rank, bool(ok)))
