@@ -113,3 +113,20 @@ def test_a_scalar_redefinition_between_the_valu_write_and_the_load_clears_the_re
     # ... but only for the registers it defines
     rows[2] = ("s_mov_b32 s6, s40", 4)
     assert len(chk.hazard_scan("k", listing(rows))) == 1
+
+
+# ---- MFMA results touched too early (asm-issued MFMAs: the compiler pads nothing) -------------------------------------------------
+def test_a_valu_read_of_an_mfma_result_needs_eleven_wait_states():
+    mf = ("v_mfma_f32_32x32x16_bf16 v[0:15], a[0:3], v[20:23], v[0:15]", 8)
+    early = [mf, ("s_nop 7", 4), ("v_sin_f32_e32 v30, v4", 4), ("s_endpgm", 4)]                  # 8 wait states
+    found = chk.mfma_result_scan("k", listing(early))
+    assert len(found) == 1 and found[0][3] == 8
+    ok = [mf, ("s_nop 7", 4), ("s_nop 2", 4), ("v_sin_f32_e32 v30, v4", 4), ("s_endpgm", 4)]     # 11
+    assert chk.mfma_result_scan("k", listing(ok)) == []
+    # accumulating into the same registers is what MFMAs do back to back; reading the result as an A / B operand is not
+    chain = [mf, mf, ("v_mfma_f32_32x32x16_bf16 v[40:55], v[0:3], v[20:23], v[40:55]", 8), ("s_endpgm", 4)]
+    found = chk.mfma_result_scan("k", listing(chain))
+    assert len(found) == 1 and "v[40:55], v[0:3]" in found[0][1]
+    # an overwrite (bias tile read from LDS into the accumulator) counts as a touch too
+    over = [mf, ("ds_read_b128 v[0:3], v60", 8), ("s_endpgm", 4)]
+    assert len(chk.mfma_result_scan("k", listing(over))) == 1

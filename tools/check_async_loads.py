@@ -242,6 +242,61 @@ def hazard_scan(name, lines):
     return found
 
 
+# ---- matrix-core results: an MFMA's destination may not be touched by anything but an accumulating MFMA too early -----------------
+# The weight-stationary and refinement INR kernels issue their MFMAs as inline asm (AGPR-pinned operands), so the compiler's own
+# padding between an MFMA and the first VALU / LDS / vector-memory instruction that reads or overwrites its result (gfx940 family:
+# passes + 3 wait states — 11 for the 8-pass 32x32x16 bf16 product; hipcc keeps 12 in the kernels it schedules itself) is the
+# kernel author's job there.  Same lesson as the SGPR hazard above: what the compiler cannot see, the build checks.  Counted
+# as LLVM counts them (one per instruction, N + 1 per s_nop N), in layout order inside a function.
+VREG = re.compile(r"\b([va])\[(\d+):(\d+)\]|\b([va])(\d+)\b")
+MFMA_RESULT_WAIT_STATES = 11
+
+
+def vregs(tok):
+    out = set()
+    for m in VREG.finditer(tok):
+        if m.group(1) is not None:
+            out.update((m.group(1), i) for i in range(int(m.group(2)), int(m.group(3)) + 1))
+        else:
+            out.add((m.group(4), int(m.group(5))))
+    return out
+
+
+def mfma_result_scan(name, lines):
+    """[(line_no, instruction, mfma, wait states)]: instructions other than an MFMA that names the same registers as its C/D
+    accumulator which read or write an MFMA's destination fewer than MFMA_RESULT_WAIT_STATES wait states after it."""
+    ins = parse(lines)
+    last, found, states = {}, [], 0
+    at = []
+    for _, _, _, text in ins:
+        at.append(states)
+        states += int(text.split()[1]) + 1 if text.startswith("s_nop") else 1
+    for i, (no, _, _, text) in enumerate(ins):
+        mn = text.split()[0]
+        ops = text.split(None, 1)[1] if " " in text else ""
+        parts = [p.strip() for p in ops.split(",")]
+        if mn.startswith("v_mfma") or mn.startswith("v_smfmac"):
+            dst = vregs(parts[0])
+            for p in parts[1:3]:                                   # A / B operands read another MFMA's result
+                for r in vregs(p):
+                    if r in last and at[i] - at[last[r]] - 1 < MFMA_RESULT_WAIT_STATES:
+                        found.append((no, text, ins[last[r]][3], at[i] - at[last[r]] - 1))
+                        break
+            for r in dst:
+                last[r] = i
+            continue
+        if mn.startswith("s_") or not ops:
+            continue
+        touched = [r for r in vregs(ops) if r in last]
+        if touched:
+            gap = min(at[i] - at[last[r]] - 1 for r in touched)
+            if gap < MFMA_RESULT_WAIT_STATES:
+                found.append((no, text, ins[last[touched[0]]][3], gap))
+        for r in vregs(parts[0]):                                  # a register redefined by something else is no MFMA result any more
+            last.pop(r, None)
+    return found
+
+
 TOOLS = ("llvm-objcopy", "clang-offload-bundler", "llvm-objdump")
 MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
 
@@ -343,7 +398,23 @@ def main():
             for no, ins, writer, ws in bad[:6]:
                 print(f"   line {no}: {writer}   ->   {ins}   ({ws} wait state(s) between)")
     print(f"check_async_loads: VALU-writes-SGPR -> VMEM hazard: {len(funcs)} kernels, {vm} vector-memory instructions, {hz} violation(s) in {hz_kernels} kernel(s)")
-    return 1 if failures or hz or not checked or not loads else 0
+    mf_kernels = mf = mfmas = 0
+    for name, lines in funcs.items():
+        if name.startswith("__"):
+            continue
+        n = sum(1 for _, t in lines if t.split("//")[0].strip().startswith("v_mfma"))
+        if not n:
+            continue
+        mfmas += n
+        bad = mfma_result_scan(name, lines)
+        if bad:
+            mf_kernels += 1
+            mf += len(bad)
+            print(f"MFMA {name}: {len(bad)} instruction(s) touch an MFMA result < {MFMA_RESULT_WAIT_STATES} wait states after it")
+            for no, ins, producer, ws in bad[:6]:
+                print(f"   line {no}: {producer[:60]}   ->   {ins}   ({ws} wait state(s) between)")
+    print(f"check_async_loads: MFMA result hazard: {mfmas} MFMAs, {mf} violation(s) in {mf_kernels} kernel(s)")
+    return 1 if failures or hz or mf or not checked or not loads else 0
 
 
 if __name__ == "__main__":
