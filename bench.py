@@ -206,7 +206,7 @@ def inr_path(dev, frames=5):
     """The other half of the north star, measured in the same run: BASELINE config 5 AS A FRAME — 256^3 x 4
     modalities (BraTS-shaped synthetic scene), 512 x 512 px, 256 samples/ray, the prediction overlay's class of
     every LIVE sample queried from a 4 x 256 SIREN on the bf16 MFMA kernel (mrirt_render_brats_inr: ERT-aware
-    passes — 64 steps on this scene, where no ray can terminate on intensity alone; 32 otherwise: plan + emit -> MLP -> composite).  HIP events around whole frames on the launch stream.
+    passes — 96 steps on this scene, where no ray can terminate on intensity alone; 32 otherwise: plan + emit -> MLP -> composite).  HIP events around whole frames on the launch stream.
     ``roofline`` prices the frame: useful flops = live (composited) samples x flop/query over the frame time.
     ``mlp_kernel`` is the MLP kernel by itself on 67.1 M resident random queries (512^2 x 256 nominal)."""
     import ctypes as C
@@ -225,7 +225,7 @@ def inr_path(dev, frames=5):
     zmu = [float(v[v != 0].mean()) for v in vols]
     zsg = [float(v[v != 0].std() + 1e-6) for v in vols]
     p5 = synth.brats_scene(n, image, steps, channels=4, show_seg=True, show_pred=True, intensity_alpha=0.4)
-    gv = [mrirt.upload_grid(v, (n, n, n), "quad") for v in vols]
+    gv = mrirt.upload_mod4(vols, (n, n, n))             # the four modalities as one float4 grid (MRIRT_LAYOUT_MOD4): 268 MB resident
     gl = mrirt.upload_grid(lab, (n, n, n), "brick")
     out = torch.empty((image, image, 4), dtype=torch.float32, device=dev)
     _, aux = inr.render_brats_inr(p5, gv, net, zmu, zsg, labels=gl, out=out, return_aux=True)     # untimed: accounting
@@ -265,7 +265,7 @@ def inr_path(dev, frames=5):
     ms_refined = timed(net.desc)
     marked = float(inr.calibration(net)["rms_error"])
     tflops = flop * nq / (ms * 1e-3) / 1e12
-    return {"workload": "C5 frame: 256^3 x 4 modalities + seg, 512x512 px, 256 samples/ray, per-sample SIREN 7->4x256->4 "
+    return {"workload": "C5 frame: 256^3 x 4 modalities (one float4 MOD4 grid) + seg, 512x512 px, 256 samples/ray, per-sample SIREN 7->4x256->4 "
                         f"(bf16 MFMA, fp32 accumulate), ERT-aware passes of {aux['chunk_steps']} steps",
             "value": round(live / (frame_ms * 1e-3) / 1e6, 1), "unit": "M live queries/s", "ms_per_frame": round(frame_ms, 3),
             "dtype": "bf16", "live_samples_per_frame": live, "mlp_queries_per_frame": queries,

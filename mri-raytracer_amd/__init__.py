@@ -17,6 +17,6 @@ from .camera import OrbitalCamera  # noqa: F401
 from .inr import apply_mlp, build_input, inr_forward, model_load, predict_volume, render_brats_inr  # noqa: F401
 from .shim import Device, KernelShim  # noqa: F401
 from .render import (Grid, detile, render_brats, render_sdf, render_volume_u8, tiles_for_rank,  # noqa: F401
-                     unbrick_grid, upload_grid, upload_label_cells)
+                     unbrick_grid, upload_grid, upload_label_cells, upload_mod4)
 
 __version__ = "0.1.0"

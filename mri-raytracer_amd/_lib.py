@@ -24,16 +24,16 @@ HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-s
 ABI_SYMBOLS = [
     "mrirt_render_brats", "mrirt_render_brats_ex", "mrirt_brats_sample_counts", "mrirt_brats_emit_samples",
     "mrirt_render_brats_stream", "mrirt_brats_inr_scratch_bytes", "mrirt_render_brats_inr", "mrirt_brick_elems", "mrirt_brick_grid",
-    "mrirt_unbrick_grid", "mrirt_vec4_elems", "mrirt_vga_elems", "mrirt_build_vec4_grid", "mrirt_build_label_cells", "mrirt_bc4_decode", "mrirt_macro_cells", "mrirt_skip_mask_words",
+    "mrirt_unbrick_grid", "mrirt_vec4_elems", "mrirt_vga_elems", "mrirt_build_vec4_grid", "mrirt_build_label_cells", "mrirt_build_mod4_grid", "mrirt_bc4_decode", "mrirt_macro_cells", "mrirt_skip_mask_words",
     "mrirt_build_macro_max", "mrirt_build_macro_labels", "mrirt_render_brats_skip", "mrirt_render_volume", "mrirt_build_cell8", "mrirt_render_sdf", "mrirt_tiles_for_rank",
     "mrirt_detile", "mrirt_inr_pack_bytes", "mrirt_inr_pack_weights", "mrirt_inr_calibrate", "mrirt_inr_forward", "mrirt_inr_forward_refined",
     "mrirt_inr_predict_volume", "mrirt_abi_version", "mrirt_status_string", "mrirt_last_hip_error",
     "mrirt_sizeof", "mrirt_brats_skip_applicable", "mrirt_brats_kernel_family", "mrirt_install_abort_trace",
 ]
 
-ABI_VERSION = 3          # MRIRT_ABI_VERSION of include/mrirt.h this binding was written against
+ABI_VERSION = 4          # MRIRT_ABI_VERSION of include/mrirt.h this binding was written against
 OK = 0
-LAYOUT_LINEAR, LAYOUT_BRICK, LAYOUT_VG, LAYOUT_QUAD, LAYOUT_VGA, LAYOUT_LABCELL = 0, 1, 2, 3, 4, 5
+LAYOUT_LINEAR, LAYOUT_BRICK, LAYOUT_VG, LAYOUT_QUAD, LAYOUT_VGA, LAYOUT_LABCELL, LAYOUT_MOD4 = 0, 1, 2, 3, 4, 5, 6
 MATH_STRICT, MATH_FAST = 0, 1
 OUT_RGBA32F, OUT_RGBA16F = 0, 1
 VOX_U32X4, VOX_U8, VOX_F32, VOX_CELL8 = 0, 1, 2, 3
@@ -260,6 +260,8 @@ def lib() -> C.CDLL:
     l.mrirt_build_vec4_grid.argtypes = [vp, vp, C.POINTER(u32), u32, vp]
     l.mrirt_build_label_cells.argtypes = [vp, vp, C.POINTER(u32), vp, vp]
     l.mrirt_build_label_cells.restype = i32
+    l.mrirt_build_mod4_grid.argtypes = [C.POINTER(vp), vp, C.POINTER(u32), vp]
+    l.mrirt_build_mod4_grid.restype = i32
     l.mrirt_macro_cells.argtypes = [C.POINTER(u32)]
     l.mrirt_macro_cells.restype = i64
     l.mrirt_skip_mask_words.argtypes = [C.POINTER(u32)]

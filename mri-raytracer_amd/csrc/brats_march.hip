@@ -742,6 +742,7 @@ struct EmitArgs {
     float* mix;                  // C5 passes: the sample's weighted intensity (float per row), or with shading
                                  // (intensity, gradient) as float4 per row; and its seg label when showSeg
     uint32_t* seg;
+    const float4* geom;          // chunked C5: per pixel (ro, rd.x), (rd.y, rd.z, t1, hit) — written once by the plan kernel
 };
 
 // MLP inputs of the sample at index-space cell `s` -> row `row` of coords / feats (shared by the one-pass and
@@ -750,12 +751,23 @@ template <bool STRICT, int LAYOUT>
 __device__ __forceinline__ void emit_row(const K1Args& a, const EmitArgs& e, const Cell& s, int64_t row, float sv[4]) {
     using Mm = M<STRICT>;
     float z[4];
-    Taps<LAYOUT, false> taps[4];
+    if constexpr (LAYOUT == MRIRT_LAYOUT_MOD4) {
+        // the four modalities are the four components of ONE float4 grid: the VG grid's eight corner gathers, and the blend
+        // its shaded form applies to (v, dx, dy, dz) — each component is sampleLinear's trilinear expression, bit for bit
+        Taps<2, true> taps;
+        taps.template issue<true>(a.vol[0], a.grid, s);
+        float g[3];
+        taps.template eval<STRICT>(s, sv[0], g);
+        sv[1] = g[0]; sv[2] = g[1]; sv[3] = g[2];
+    } else {
+        Taps<LAYOUT, false> taps[4];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) taps[m].template issue<true>(a.vol[m], a.grid, s);      // all gathers in flight first (layouts 0..3)
+        for (int m = 0; m < 4; ++m) taps[m].template issue<true>(a.vol[m], a.grid, s);      // all gathers in flight first (layouts 0..3)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) taps[m].template eval<STRICT>(s, sv[m], nullptr);
+    }
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-        taps[m].template eval<STRICT>(s, sv[m], nullptr);
         const float v = sv[m];
         z[m] = STRICT ? Mm::divu_data(v - e.zmu[m], e.zsigma[m]) : (v - e.zmu[m]) * e.zsigma[m].r;
     }
@@ -850,8 +862,12 @@ __device__ __forceinline__ void c5_plan_rows(const K1Args& a, bool mine, int64_t
         if (cnt > k) rowOwner[rows.row] = make_uint2((uint32_t)pix, __float_as_uint(t));   // stores only: nothing waits on them
 }
 
-__global__ __launch_bounds__(256) void c5_plan_kernel(const K1Args a, C5Ray* __restrict__ rays, uint2* __restrict__ rowOwner,
-                                                      uint32_t* __restrict__ counter, uint32_t chunk) {
+// The ray of every pixel is set up ONCE per frame, here: origin, direction, exit distance and whether it marches go to
+// `geom` (two float4 per pixel), which the emission reads per row and the composite kernel per ray and pass.  Setting the ray
+// up again for each of its samples was a quarter of the emission's instructions (11 IEEE divisions and two square roots
+// against the sample's own three).
+__global__ __launch_bounds__(256) void c5_plan_kernel(const K1Args a, C5Ray* __restrict__ rays, float4* __restrict__ geom,
+                                                      uint2* __restrict__ rowOwner, uint32_t* __restrict__ counter, uint32_t chunk) {
     uint32_t px, py;
     int64_t oidx;
     const bool mine = map_pixel(a.map, px, py, oidx) == 1;
@@ -861,8 +877,11 @@ __global__ __launch_bounds__(256) void c5_plan_kernel(const K1Args a, C5Ray* __r
     bool goes = false;
     if (mine) {
         float ro[3], rd[3], t0;
-        goes = setup_ray(a, px, py, ro, rd, t0, t1) && r.T > a.ert;
+        const bool hit = setup_ray(a, px, py, ro, rd, t0, t1);
+        goes = hit && r.T > a.ert;
         r.t = t0;
+        geom[2 * pix] = make_float4(ro[0], ro[1], ro[2], rd[0]);
+        geom[2 * pix + 1] = make_float4(rd[1], rd[2], t1, hit ? 1.0f : 0.0f);
     }
     c5_plan_rows(a, mine, pix, r, goes, t1, rays, rowOwner, counter, chunk);
 }
@@ -872,16 +891,25 @@ __global__ __launch_bounds__(256) void c5_plan_kernel(const K1Args a, C5Ray* __r
 // memory latency with one wave per SIMD slot to hide it (measured: 0.18 ms per pass at 512^2, 1.6 ms of a
 // 10.5 ms frame).  The rows of a wave are the same step of neighbouring rays (C5Rows), so the gathers stay as
 // coherent as the march's own and the stores are contiguous; the plan recorded each row's pixel and t.
+#ifndef MRIRT_EMIT_RUN
+#define MRIRT_EMIT_RUN 8
+#endif
+constexpr uint32_t kEmitRun = MRIRT_EMIT_RUN;
 template <bool STRICT, int LAYOUT, bool SHADE>
 __global__ __launch_bounds__(256) void c5_emit_kernel(const K1Args a, const EmitArgs e, const uint2* __restrict__ rowOwner,
                                                       const uint32_t* __restrict__ counter) {
     using Mm = M<STRICT>;
-    const uint32_t n = *counter;
-    for (uint32_t row = blockIdx.x * blockDim.x + threadIdx.x; row < n; row += gridDim.x * blockDim.x) {
+    const uint32_t n = *counter, nGroups = (n + 255u) >> 8;
+    // a workgroup takes kEmitRun consecutive 256-row groups at a time: the rows of a wave's rays follow one another step by
+    // step (C5Rows), so a run is ~kEmitRun * 4 consecutive steps of the same 64 rays and their gathers hit the lines the
+    // previous steps brought into this CU's L1 (a plain grid stride sent every fifth step of a bundle to another CU)
+    for (uint32_t g0 = blockIdx.x * kEmitRun; g0 < nGroups; g0 += gridDim.x * kEmitRun)
+    for (uint32_t j = 0; j < kEmitRun && g0 + j < nGroups; ++j) {
+        const uint32_t row = ((g0 + j) << 8) + threadIdx.x;
+        if (row >= n) break;
         const uint2 own = rowOwner[row];
-        const uint32_t py = own.x / a.map.width, px = own.x - py * a.map.width;
-        float ro[3], rd[3], t0, t1;
-        setup_ray(a, px, py, ro, rd, t0, t1);
+        const float4 ga = e.geom[2 * (size_t)own.x], gb = e.geom[2 * (size_t)own.x + 1];
+        const float ro[3] = { ga.x, ga.y, ga.z }, rd[3] = { ga.w, gb.x, gb.y };
         const float t = __uint_as_float(own.y);
         Cell s;
         locate<STRICT>(a, ro, rd, t, s);
@@ -914,7 +942,7 @@ __global__ __launch_bounds__(256) void c5_emit_kernel(const K1Args a, const Emit
 // records (class from the MLP; intensity, gradient and seg label from the emission) — no volume access, and the
 // next step's records are in flight while this step composites.
 template <bool STRICT, bool SHADE>
-__global__ __launch_bounds__(256) void c5_composite_kernel(const K1Args a, C5Ray* __restrict__ rays,
+__global__ __launch_bounds__(256) void c5_composite_kernel(const K1Args a, C5Ray* __restrict__ rays, const float4* __restrict__ geom,
                                                            const int16_t* __restrict__ classes,
                                                            const float* __restrict__ mix, const uint32_t* __restrict__ seg,
                                                            uint2* __restrict__ rowOwner, uint32_t* __restrict__ nextCounter,
@@ -932,8 +960,10 @@ __global__ __launch_bounds__(256) void c5_composite_kernel(const K1Args a, C5Ray
     if (kind == 1) {
         st = rays[pix];
         r.C0 = st.C0; r.C1 = st.C1; r.C2 = st.C2; r.T = st.T;
-        float ro[3], t0;
-        if (nextCounter != nullptr || (SHADE && st.cnt != 0)) hit = setup_ray(a, px, py, ro, rd, t0, t1);
+        if (nextCounter != nullptr || (SHADE && st.cnt != 0)) {
+            const float4 g0 = geom[2 * pix], g1 = geom[2 * pix + 1];
+            rd[0] = g0.w; rd[1] = g1.x; rd[2] = g1.y; t1 = g1.z; hit = g1.w != 0.0f;
+        }
     }
     struct Rec { float v, g[3]; Labels lb; };
     auto fetch = [&](uint32_t row, bool takes, Rec& c) {
@@ -978,7 +1008,7 @@ struct Prepared { uint32_t layout, math; bool shade, pipe, slab, ring; };
 // validate + fill the kernel arguments shared by every K1 entry point
 static int prepare(const MrirtBratsParams* p, const MrirtRenderExt* ext, const void* const vol[4],
                    const void* labels, const void* preds, bool needVolumes, int64_t pitch_px,
-                   K1Args& a, Prepared& cfg) {
+                   K1Args& a, Prepared& cfg, bool allowMod4 = false) {
     if (!p || (needVolumes && !vol)) return MRIRT_ERR_NULL;
     for (int k = 0; k < 3; ++k) if (p->dims[k] < 2) return MRIRT_ERR_DIMS;
     const uint32_t layout = ext ? ext->layout : (uint32_t)MRIRT_LAYOUT_LINEAR;
@@ -987,7 +1017,8 @@ static int prepare(const MrirtBratsParams* p, const MrirtRenderExt* ext, const v
     const uint32_t fmt = ext ? ext->outFormat : (uint32_t)MRIRT_OUT_RGBA32F;
     const uint32_t variant = ext ? ext->kernelVariant : 0u;
     const bool labCells = labLayout == MRIRT_LAYOUT_LABCELL;              // both overlays' corner labels per cell: QUAD grids only
-    if (layout > MRIRT_LAYOUT_VGA || (labLayout > MRIRT_LAYOUT_BRICK && !labCells) || math > MRIRT_MATH_FAST || fmt > MRIRT_OUT_RGBA16F)
+    const bool mod4 = layout == MRIRT_LAYOUT_MOD4 && allowMod4;          // all four modalities in one float4 grid: mrirt_render_brats_inr only
+    if ((layout > MRIRT_LAYOUT_VGA && !mod4) || (labLayout > MRIRT_LAYOUT_BRICK && !labCells) || math > MRIRT_MATH_FAST || fmt > MRIRT_OUT_RGBA16F)
         return MRIRT_ERR_LAYOUT;
     if (labCells && layout != MRIRT_LAYOUT_QUAD) return MRIRT_ERR_LAYOUT;
     if (labCells && mrirt_vec4_elems(p->dims) >= (int64_t)1 << 29) return MRIRT_ERR_DIMS;      // 32-bit byte offsets of 8-byte elements
@@ -996,7 +1027,7 @@ static int prepare(const MrirtBratsParams* p, const MrirtRenderExt* ext, const v
     if (mrirt_brick_elems(p->dims) >= (int64_t)1 << 32 || mrirt_vec4_elems(p->dims) >= (int64_t)1 << 32)
         return MRIRT_ERR_DIMS;                                           // 32-bit element offsets
     if (needVolumes) {
-        for (int m = 0; m < 4; ++m) if (p->volEnabled[m] != 0 && !vol[m]) return MRIRT_ERR_NULL;
+        for (int m = 0; m < (mod4 ? 1 : 4); ++m) if ((mod4 || p->volEnabled[m] != 0) && !vol[m]) return MRIRT_ERR_NULL;
         if ((p->showSeg != 0 || (labCells && p->showPred != 0)) && !labels) return MRIRT_ERR_NULL;
     }
     {
@@ -1047,7 +1078,7 @@ static int prepare(const MrirtBratsParams* p, const MrirtRenderExt* ext, const v
                             // 16-px workgroups of VGA grids it measured 1.3 % slower (C3), so those keep straight bands.  Bit 9 flips it.
                             ((variant & 512u) == 0u) != bigBlocks);
     if (rc != MRIRT_OK) return rc;
-    fill_grid_dims(a.grid, p->dims, layout == MRIRT_LAYOUT_VGA ? (uint32_t)MRIRT_LAYOUT_VG : layout);
+    fill_grid_dims(a.grid, p->dims, (layout == MRIRT_LAYOUT_VGA || mod4) ? (uint32_t)MRIRT_LAYOUT_VG : layout);
     fill_vga_dims(a.vga, p->dims);
     fill_label_addr(a.lab, p->dims, labCells ? (uint32_t)MRIRT_LAYOUT_LINEAR : labLayout);
     for (int k = 0; k < 3; ++k) {
@@ -1384,7 +1415,7 @@ extern "C" int mrirt_brats_emit_samples(const MrirtBratsParams* p, const MrirtRe
     EmitArgs e;
     for (int m = 0; m < 4; ++m) { e.zmu[m] = zmu[m]; e.zsigma[m] = make_udiv(zsigma[m]); }
     for (int k = 0; k < 3; ++k) { e.dimM1[k] = (double)(p->dims[k] - 1); e.rdimM1[k] = 1.0 / e.dimM1[k]; }
-    e.offsets = offsets; e.coords = coords; e.feats = reinterpret_cast<float4*>(feats); e.mix = nullptr; e.seg = nullptr;
+    e.offsets = offsets; e.coords = coords; e.feats = reinterpret_cast<float4*>(feats); e.mix = nullptr; e.seg = nullptr; e.geom = nullptr;
     hipStream_t s = static_cast<hipStream_t>(stream);
     return cfg.math == MRIRT_MATH_STRICT ? launch_emit<true>(a, e, cfg.layout, s) : launch_emit<false>(a, e, cfg.layout, s);
 }
@@ -1405,7 +1436,7 @@ __global__ void c5_sum_kernel(const uint32_t* __restrict__ counters, uint32_t n,
     if (threadIdx.x == 0) atomicAdd(reinterpret_cast<unsigned long long*>(queries), (unsigned long long)s);
 }
 
-struct C5Scratch { uint32_t* counters; C5Ray* rays; uint2* rowOwner; float* coords; float* feats; float* mix; uint32_t* seg; int16_t* classes; int64_t cap, bytes; };
+struct C5Scratch { uint32_t* counters; C5Ray* rays; float4* geom; uint2* rowOwner; float* coords; float* feats; float* mix; uint32_t* seg; int16_t* classes; int64_t cap, bytes; };
 
 static int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
 
@@ -1417,8 +1448,9 @@ static int c5_carve(const MrirtBratsParams* p, uint32_t chunk, void* base, C5Scr
     if (sc.cap >= ((int64_t)1 << 32) - ((int64_t)1 << 21)) return MRIRT_ERR_ARG;   // 32-bit row numbers per pass (+ one grid stride of headroom)
     char* b = static_cast<char*>(base);
     int64_t o = 0;
-    sc.counters = reinterpret_cast<uint32_t*>(b + o); o += align256((int64_t)kC5MaxPasses * 4);
+    sc.counters = reinterpret_cast<uint32_t*>(b + o); o += align256((int64_t)kC5MaxPasses * 8);     // batch sizes, then the refinement's segment tickets
     sc.rays = reinterpret_cast<C5Ray*>(b + o);        o += align256(px * (int64_t)sizeof(C5Ray));
+    sc.geom = reinterpret_cast<float4*>(b + o);       o += align256(px * 32);
     sc.rowOwner = reinterpret_cast<uint2*>(b + o);    o += align256(sc.cap * 8);
     sc.coords = reinterpret_cast<float*>(b + o);      o += align256(sc.cap * 12);
     sc.feats = reinterpret_cast<float*>(b + o);       o += align256(sc.cap * 16);
@@ -1432,12 +1464,13 @@ static int c5_carve(const MrirtBratsParams* p, uint32_t chunk, void* base, C5Scr
 template <bool STRICT>
 static int c5_launch_plan(const K1Args& a, const EmitArgs& e, uint32_t layout, bool shade, const C5Scratch& sc, uint32_t pass,
                           uint32_t chunk, hipStream_t s) {
-    // the C5 passes read LINEAR / BRICK / VG / QUAD grids; QUAD carries no gradients
-    if (layout > MRIRT_LAYOUT_QUAD || (layout == MRIRT_LAYOUT_QUAD && shade)) return MRIRT_ERR_LAYOUT;
+    // the C5 passes read LINEAR / BRICK / VG / QUAD / MOD4 grids; QUAD and MOD4 carry no gradients
+    const bool flat = layout == MRIRT_LAYOUT_QUAD || layout == MRIRT_LAYOUT_MOD4;
+    if ((layout > MRIRT_LAYOUT_QUAD && layout != MRIRT_LAYOUT_MOD4) || (flat && shade)) return MRIRT_ERR_LAYOUT;
     uint32_t* counter = sc.counters + pass;
     if (pass == 0) {                                                  // later passes are planned by the composite kernel
         hipLaunchKernelGGL(c5_plan_kernel, dim3(a.map.chunk * kXcds), dim3(a.map.blockPx == 8 ? 64 : 256), 0, s,
-                           a, sc.rays, sc.rowOwner, counter, chunk);
+                           a, sc.rays, sc.geom, sc.rowOwner, counter, chunk);
         MRIRT_HIP(hipGetLastError());
     }
     const int64_t blocksWanted = (sc.cap + 255) / 256;
@@ -1447,6 +1480,7 @@ static int c5_launch_plan(const K1Args& a, const EmitArgs& e, uint32_t layout, b
         case MRIRT_LAYOUT_LINEAR: if (shade) MRIRT_C5E(0, true); else MRIRT_C5E(0, false); break;
         case MRIRT_LAYOUT_BRICK:  if (shade) MRIRT_C5E(1, true); else MRIRT_C5E(1, false); break;
         case MRIRT_LAYOUT_VG:     if (shade) MRIRT_C5E(2, true); else MRIRT_C5E(2, false); break;
+        case MRIRT_LAYOUT_MOD4:   MRIRT_C5E(MRIRT_LAYOUT_MOD4, false); break;
         default:                  MRIRT_C5E(3, false); break;
     }
 #undef MRIRT_C5E
@@ -1457,8 +1491,8 @@ static int c5_launch_plan(const K1Args& a, const EmitArgs& e, uint32_t layout, b
 template <bool STRICT>
 static int c5_launch_composite(const K1Args& a, bool shade, const C5Scratch& sc, uint32_t* nextCounter, uint32_t chunk, hipStream_t s) {
     const dim3 grid(a.map.chunk * kXcds), block(a.map.blockPx == 8 ? 64 : 256);     // the plan kernel's pixel -> lane map
-    if (shade) hipLaunchKernelGGL((c5_composite_kernel<STRICT, true>), grid, block, 0, s, a, sc.rays, sc.classes, sc.mix, sc.seg, sc.rowOwner, nextCounter, chunk);
-    else       hipLaunchKernelGGL((c5_composite_kernel<STRICT, false>), grid, block, 0, s, a, sc.rays, sc.classes, sc.mix, sc.seg, sc.rowOwner, nextCounter, chunk);
+    if (shade) hipLaunchKernelGGL((c5_composite_kernel<STRICT, true>), grid, block, 0, s, a, sc.rays, sc.geom, sc.classes, sc.mix, sc.seg, sc.rowOwner, nextCounter, chunk);
+    else       hipLaunchKernelGGL((c5_composite_kernel<STRICT, false>), grid, block, 0, s, a, sc.rays, sc.geom, sc.classes, sc.mix, sc.seg, sc.rowOwner, nextCounter, chunk);
     MRIRT_HIP(hipGetLastError());
     return MRIRT_OK;
 }
@@ -1475,12 +1509,13 @@ extern "C" int mrirt_render_brats_inr(const MrirtBratsParams* p, const MrirtRend
                                       uint32_t chunk_steps, void* scratch, int64_t scratch_bytes,
                                       void* out_rgba, int64_t pitch_px, uint64_t* stats_dev, void* stream) {
     if (!out_rgba || !scratch || !net || !vol || !zmu || !zsigma) return MRIRT_ERR_NULL;
-    for (int m = 0; m < 4; ++m) if (!vol[m]) return MRIRT_ERR_NULL;           // the MLP reads all four modalities
+    const bool mod4 = ext && ext->layout == MRIRT_LAYOUT_MOD4;
+    for (int m = 0; m < (mod4 ? 1 : 4); ++m) if (!vol[m]) return MRIRT_ERR_NULL;     // the MLP reads all four modalities
     if (ext && ext->tileSize != 0) return MRIRT_ERR_ARG;                      // whole-frame only
     if ((net->kind != MRIRT_INR_FOURIER_RELU && net->kind != MRIRT_INR_SIREN) || net->numMods != 4) return MRIRT_ERR_ARG;
     K1Args a;
     Prepared cfg;
-    int rc = prepare(p, ext, vol, labels, nullptr, true, pitch_px, a, cfg);
+    int rc = prepare(p, ext, vol, labels, nullptr, true, pitch_px, a, cfg, true);
     if (rc != MRIRT_OK) return rc;
     if (a.labCell != nullptr) return MRIRT_ERR_LAYOUT;           // the C5 passes read the ground-truth grid themselves (LINEAR / BRICK)
     if (p->showPred == 0) return MRIRT_ERR_ARG;
@@ -1508,17 +1543,17 @@ extern "C" int mrirt_render_brats_inr(const MrirtBratsParams* p, const MrirtRend
     EmitArgs e;
     for (int m = 0; m < 4; ++m) { e.zmu[m] = zmu[m]; e.zsigma[m] = make_udiv(zsigma[m]); }
     for (int k = 0; k < 3; ++k) { e.dimM1[k] = (double)(p->dims[k] - 1); e.rdimM1[k] = 1.0 / e.dimM1[k]; }
-    e.offsets = nullptr; e.coords = sc.coords; e.feats = reinterpret_cast<float4*>(sc.feats); e.mix = sc.mix; e.seg = sc.seg;
+    e.offsets = nullptr; e.coords = sc.coords; e.feats = reinterpret_cast<float4*>(sc.feats); e.mix = sc.mix; e.seg = sc.seg; e.geom = sc.geom;
     a.out = out_rgba;
     a.stats = stats_dev;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    MRIRT_HIP(hipMemsetAsync(sc.counters, 0, (size_t)kC5MaxPasses * 4, s));
+    MRIRT_HIP(hipMemsetAsync(sc.counters, 0, (size_t)kC5MaxPasses * 8, s));
     const bool strict = cfg.math == MRIRT_MATH_STRICT;
     for (uint32_t c = 0; c < (uint32_t)passes; ++c) {
         rc = strict ? c5_launch_plan<true>(a, e, cfg.layout, cfg.shade, sc, c, chunk_steps, s)
                     : c5_launch_plan<false>(a, e, cfg.layout, cfg.shade, sc, c, chunk_steps, s);
         if (rc != MRIRT_OK) return rc;
-        rc = inr_forward_dev_n(net, sc.coords, sc.feats, sc.cap, sc.counters + c, sc.classes, s);
+        rc = inr_forward_dev_n(net, sc.coords, sc.feats, sc.cap, sc.counters + c, sc.classes, sc.counters + kC5MaxPasses + c, s);
         if (rc != MRIRT_OK) return rc;
         uint32_t* next = c + 1 < (uint32_t)passes ? sc.counters + c + 1 : nullptr;
         rc = strict ? c5_launch_composite<true>(a, cfg.shade, sc, next, chunk_steps, s)

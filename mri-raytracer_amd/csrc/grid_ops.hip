@@ -266,6 +266,37 @@ extern "C" int mrirt_build_vec4_grid(const float* linear, void* vec4_grid, const
     return MRIRT_OK;
 }
 
+// MOD4 (include/mrirt.h): the four modalities' values of a voxel as one float4, elements in the VG grid's order
+__global__ __launch_bounds__(256) void mod4_build_kernel(const float* __restrict__ m0, const float* __restrict__ m1,
+                                                         const float* __restrict__ m2, const float* __restrict__ m3, float4* __restrict__ dst,
+                                                         uint32_t X, uint32_t Y, uint32_t Z, uint32_t nbx, uint32_t nby, uint64_t total) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;      // float4 index in dst
+    if (e >= total) return;
+    const uint32_t in = (uint32_t)(e & 7u);
+    const uint64_t b = e >> 3;
+    const uint32_t bx = (uint32_t)(b % nbx), by = (uint32_t)((b / nbx) % nby), bz = (uint32_t)(b / ((uint64_t)nbx * nby));
+    const uint32_t x = bx * 2 + (in & 1u), y = by * 2 + ((in >> 1) & 1u), z = bz * 2 + (in >> 2);
+    float4 o = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (x < X && y < Y && z < Z) {
+        const uint64_t i = x + (uint64_t)y * X + (uint64_t)z * X * Y;
+        o = make_float4(m0[i], m1[i], m2[i], m3[i]);
+    }
+    dst[e] = o;
+}
+
+extern "C" int mrirt_build_mod4_grid(const float* const linear[4], void* mod4_grid, const uint32_t dims[3], void* stream) {
+    if (!linear || !mod4_grid || !dims) return MRIRT_ERR_NULL;
+    for (int m = 0; m < 4; ++m) if (!linear[m]) return MRIRT_ERR_NULL;
+    for (int k = 0; k < 3; ++k) if (dims[k] < 2) return MRIRT_ERR_DIMS;
+    const uint32_t nbx = (dims[0] + 1) / 2, nby = (dims[1] + 1) / 2;
+    const uint64_t total = (uint64_t)mrirt_vec4_elems(dims);
+    if (total >= (1ull << 32)) return MRIRT_ERR_DIMS;
+    hipLaunchKernelGGL(mod4_build_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       linear[0], linear[1], linear[2], linear[3], static_cast<float4*>(mod4_grid), dims[0], dims[1], dims[2], nbx, nby, total);
+    MRIRT_HIP(hipGetLastError());
+    return MRIRT_OK;
+}
+
 // LABCELL (include/mrirt.h): per voxel = cell base, the nearest-label candidates of BOTH label grids: the labels of the cell's
 // eight corners as nibbles (corner (dx,dy,dz) at bits 4 (dx + 2 dy + 4 dz), neighbours clamped, labels >= 8 -> 8: the shader
 // draws 1..7 only), .x ground truth, .y prediction; elements in the QUAD grid's order.

@@ -42,6 +42,7 @@ template <int N> struct IC { static constexpr int value = N; };   // compile-tim
 constexpr int kInrWaves = 8;      // waves per workgroup
 constexpr int kMaxLayers = 8;
 constexpr int kPackSlackFrags = 64;   // one full chunk
+constexpr int kRefSlackFrags = 32;    // after the refine image: inr_refine_kernel's tile DMAs always move a full ring slot
 constexpr int kRawStride = 12;        // floats per point in the LDS copy of the raw inputs: c0..c2, m0..m7, 0
 constexpr int kMaxMods = 8;
 
@@ -111,7 +112,7 @@ static int make_layout(const MrirtInrDesc* d, InrLayout& L) {
 // first fragment of the refine image / of the calibration record inside the packed buffer
 static inline uint32_t ref_base_frag(const InrLayout& L) { return L.totalFrags + (uint32_t)kPackSlackFrags; }
 __device__ __forceinline__ uint32_t ref_base_frag_dev(const InrLayout& L) { return L.totalFrags + (uint32_t)kPackSlackFrags; }
-static inline uint32_t tail_frag(const InrLayout& L) { return ref_base_frag(L) + L.refTotalFrags; }
+static inline uint32_t tail_frag(const InrLayout& L) { return ref_base_frag(L) + L.refTotalFrags + (uint32_t)kRefSlackFrags; }
 
 __device__ __forceinline__ uint16_t bf16_bits(float x) {     // round-to-nearest-even, NaN preserved by the cast
     return __builtin_bit_cast(uint16_t, (__bf16)x);
@@ -217,6 +218,9 @@ struct InrArgs {
     const float* tie;          // calibration record of the packed net (tail[0] = rms logit error); nullptr: no marking
     float tieScale;            // mark when (best - second) < tieScale * tie[0]
     uint32_t refineAll;        // inr_refine_kernel: every point, not only the marked ones (calibration, mrirt_inr_forward_refined)
+    uint32_t* segTicket;       // inr_refine_kernel: optional zeroed device word — the 1024-point segments after each workgroup's first are
+                               // dealt on demand instead of round-robin (the config-5 passes: a few batches per workgroup, where the
+                               // spread of the mark counts costs a whole batch time)
     uint32_t flags;            // MrirtInrFlags of the descriptor (read by the launchers only)
     float tieSigmas;           // the descriptor's; 0 = kTieSigmas
 };
@@ -1150,6 +1154,13 @@ __global__ __launch_bounds__(256, 1) void inr_ws_kernel(const InrArgs a) {
 // atomics on global memory, nothing for the host to size.
 // =====================================================================================================
 constexpr int kRefWaves = 4;
+// Diagnostic build (-DMRIRT_REF_STAMPS): s_memtime at the phase boundaries of every workgroup's second batch goes to the logits
+// buffer (which then holds no logits): [block][wave][64] uint64, decoded by tools/refine_stamps.py.  Never in the product.
+#ifdef MRIRT_REF_STAMPS
+#define REF_STAMP(k) do { if (batchNo == 1u && lane == 0) reinterpret_cast<unsigned long long*>(a.logits)[((size_t)blockIdx.x * 4 + waveS) * 64 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define REF_STAMP(k) do { } while (0)
+#endif
 
 template <int HID, int KT0, bool SIREN, bool AUG>
 __global__ __launch_bounds__(256, 1) void inr_refine_kernel(const InrArgs a) {
@@ -1168,7 +1179,7 @@ __global__ __launch_bounds__(256, 1) void inr_refine_kernel(const InrArgs a) {
     constexpr int kListCap = kBatch + kSeg;
     constexpr int kBiasQ = kMaxLayers * 256 / 4, kTabQ = 128, kRawQ = kRefWaves * 32 * kRawStride / 4;
     constexpr int kWQ = NBUF * FMAX * 64;
-    __shared__ uint4 ldsAll[kWQ + kBiasQ + kTabQ + kRawQ + kListCap / 4 + 1];       // ONE LDS object (guide: a second one de-pipelines the DMA)
+    __shared__ uint4 ldsAll[kWQ + kBiasQ + kTabQ + kRawQ + kListCap / 4 + 1];       // ONE LDS object (guide: a second one de-pipelines the DMA); the last uint4: listCount[0..1]
     const float4* ldsBias = reinterpret_cast<const float4*>(ldsAll + kWQ);
     float4* ldsTab = reinterpret_cast<float4*>(ldsAll + kWQ + kBiasQ);
     float* ldsRaw = reinterpret_cast<float*>(ldsAll + kWQ + kBiasQ + kTabQ);
@@ -1228,25 +1239,47 @@ __global__ __launch_bounds__(256, 1) void inr_refine_kernel(const InrArgs a) {
     uint32_t isLayer = 0, isTile = 0, isFrag = a.L.refFragOff[0];     // the next tile to ISSUE (scalars)
     uint32_t ringIssue = 0, ringRead = 0;                              // ring slots: next to fill / being read
     bool primed = false;
-    auto issue_tile = [&]() {
-        const uint32_t last = a.L.numLayers - 1;
-        const int nfr = isLayer == 0 ? C0 * F0 : FH;
-#pragma unroll
-        for (int i = 0; i < PERW; ++i) {
-            const int f = (int)waveS + i * kRefWaves;                 // fragment f of the tile -> slot f of the ring buffer
-            const int fs = f < nfr ? f : nfr - 1;                     // short tiles: repeat the last fragment (slot unused)
-            // Issued as inline asm ON PURPOSE: told about an LDS-DMA, hipcc makes the next ds_read whose address it cannot
-            // tell apart from the DMA's target (a ring slot chosen at run time) wait vmcnt(0) — the whole look-ahead drained
-            // once per tile (seen in the ISA of the builtin form).  The waits for these loads are the counted ones in
-            // tile_done(); hipcc's own counted waits (for the batch's input loads) can only over-wait, never under-wait.
-            const char* src = reinterpret_cast<const char*>(wr) + ((size_t)(isFrag + (uint32_t)fs) << 10) + (lane << 4);
-            const uint32_t dst = __builtin_amdgcn_readfirstlane(ldsBase + ((ringIssue * FMAX + (uint32_t)f) << 10));   // wave-uniform; the DMA adds lane * 16
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(dst) : "memory", "m0");
+    uint32_t batchNo = 0;
+    // One tile's DMAs in PERW parts, so that the hidden layers can place them in the shadows of their MFMAs: a lone wave issues
+    // an instruction every ~8 cycles, and the all-at-once form with its per-DMA address arithmetic (64 instructions) held the
+    // MFMAs up for 520 cycles per tile (s_memtime stamps, round 4).  Wave w moves fragments w * PERW .. w * PERW + PERW - 1 of the
+    // tile into the slots of the same numbers: ONE address register pair and one M0 value per four parts plus the instruction's
+    // immediate offset, which the hardware adds to the global AND the LDS address.  Every tile moves a full ring slot (FMAX
+    // fragments): a short tile (layer 0's) drags the fragments that follow it into slots nobody reads, and the image ends in
+    // kRefSlackFrags of slack for the last one.
+    static_assert(FMAX <= kRefSlackFrags, "the slack after the refine image covers one ring slot");
+    const char* curSrc = nullptr;                                     // this wave's first fragment of the tile being issued (+ lane * 16)
+    uint32_t curDst = 0;                                              // its ring slot (LDS byte address)
+    auto issue_begin = [&]() {
+        curSrc = reinterpret_cast<const char*>(wr) + ((size_t)(isFrag + waveS * PERW) << 10) + (lane << 4);
+        curDst = __builtin_amdgcn_readfirstlane(ldsBase + ((ringIssue * FMAX + waveS * PERW) << 10));
+    };
+    auto issue_part = [&](int i) {                                    // (a constant once the caller's loop is unrolled)
+        // Issued as inline asm ON PURPOSE: told about an LDS-DMA, hipcc makes the next ds_read whose address it cannot
+        // tell apart from the DMA's target (a ring slot chosen at run time) wait vmcnt(0) — the whole look-ahead drained
+        // once per tile (seen in the ISA of the builtin form).  The waits for these loads are the counted ones in
+        // tile_done(); hipcc's own counted waits (for the batch's input loads) can only over-wait, never under-wait.
+        const char* src = curSrc + (i >> 2) * 4096;
+        const uint32_t dst = curDst + (uint32_t)((i >> 2) * 4096);
+        switch (i & 3) {
+            case 0:  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(dst) : "memory", "m0"); break;
+            case 1:  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off offset:1024" :: "v"(src), "s"(dst) : "memory", "m0"); break;
+            case 2:  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off offset:2048" :: "v"(src), "s"(dst) : "memory", "m0"); break;
+            default: asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off offset:3072" :: "v"(src), "s"(dst) : "memory", "m0"); break;
         }
-        isFrag += (uint32_t)nfr;
+    };
+    auto issue_end = [&]() {
+        const uint32_t last = a.L.numLayers - 1;
+        isFrag += isLayer == 0 ? (uint32_t)(C0 * F0) : (uint32_t)FH;
         const uint32_t tilesHere = isLayer == 0 ? (uint32_t)(KT / C0) : (isLayer == last ? 1u : (uint32_t)KT);
         if (++isTile == tilesHere) { isTile = 0; if (++isLayer > last) { isLayer = 0; isFrag = a.L.refFragOff[0]; } }
         ringIssue = ringIssue + 1 == NBUF ? 0u : ringIssue + 1;
+    };
+    auto issue_tile = [&]() {
+        issue_begin();
+#pragma unroll
+        for (int i = 0; i < PERW; ++i) issue_part(i);
+        issue_end();
     };
     // end of a tile: this wave's pieces of the NEXT tile have landed (the two after it may still be in flight), its own
     // LDS reads of this tile have retired; after the barrier that holds for every wave
@@ -1333,7 +1366,14 @@ __global__ __launch_bounds__(256, 1) void inr_refine_kernel(const InrArgs a) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                    // first tile in LDS for every wave (and table + biases + list on the first batch)
 
-        bf16x8 Hc_hi[KT][2], Hc_lo[KT][2], Hn_hi[KT][2], Hn_lo[KT][2];
+        // the activations of two layers, hi and lo halves of the split, as PACKED 32-bit words (two bf16 each; word j of
+        // [tile][0..7] = elements 2j, 2j + 1 of the tile's 16 per lane).  Written a word at a time by act_pair: element-wise
+        // inserts into bf16x8 made hipcc keep every value as an fp32 register until its partner arrived and convert again
+        // at the layer's end (round 4: 417 + 161 registers, 128 v_cvt_pk and as many v_accvgpr moves per layer).
+        uint32_t Hc_hi[KT][8], Hc_lo[KT][8], Hn_hi[KT][8], Hn_lo[KT][8];
+        auto b_frag = [&](const uint32_t (&hw)[8], int s2) {
+            return __builtin_bit_cast(bf16x8, make_uint4(hw[4 * s2], hw[4 * s2 + 1], hw[4 * s2 + 2], hw[4 * s2 + 3]));
+        };
         auto bias_tile = [&](uint32_t layerOff, int o) {
             f32x16 acc;
 #pragma unroll
@@ -1343,25 +1383,21 @@ __global__ __launch_bounds__(256, 1) void inr_refine_kernel(const InrArgs a) {
             }
             return acc;
         };
-        // activation, then the split of the result: hi = bf16(x), lo = bf16(x - hi)
+        // activation of elements i, i + 1 (i even), then the split of the results: hi = bf16(x), lo = bf16(x - hi)
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        auto act_pair = [&](const f32x16& acc, int o, int i) {
+            float x0 = acc[i], x1 = acc[i + 1];
+            if constexpr (SIREN) { x0 = __builtin_amdgcn_sinf(x0); x1 = __builtin_amdgcn_sinf(x1); }
+            else { x0 = fmaxf(x0, 0.0f); x1 = fmaxf(x1, 0.0f); }
+            const bf16x2 hi = { (__bf16)x0, (__bf16)x1 };
+            const uint32_t hp = __builtin_bit_cast(uint32_t, hi);
+            const bf16x2 lo = { (__bf16)(x0 - __builtin_bit_cast(float, hp << 16)), (__bf16)(x1 - __builtin_bit_cast(float, hp & 0xffff0000u)) };
+            Hn_hi[o][i >> 1] = hp;
+            Hn_lo[o][i >> 1] = __builtin_bit_cast(uint32_t, lo);
+        };
         auto activate = [&](const f32x16& acc, int o) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                float x = acc[i];
-                if constexpr (SIREN) x = __builtin_amdgcn_sinf(x);
-                else x = fmaxf(x, 0.0f);
-                const __bf16 hi = (__bf16)x;
-                Hn_hi[o][i >> 3][i & 7] = hi;
-                Hn_lo[o][i >> 3][i & 7] = (__bf16)(x - (float)hi);
-            }
-        };
-        auto act_one = [&](const f32x16& acc, int o, int i) {
-            float x = acc[i];
-            if constexpr (SIREN) x = __builtin_amdgcn_sinf(x);
-            else x = fmaxf(x, 0.0f);
-            const __bf16 hi = (__bf16)x;
-            Hn_hi[o][i >> 3][i & 7] = hi;
-            Hn_lo[o][i >> 3][i & 7] = (__bf16)(x - (float)hi);
+            for (int i = 0; i < 16; i += 2) act_pair(acc, o, i);
         };
         // the three products of one k step (small terms first)
         auto mfma3 = [&](f32x16& acc, const bf16x8& whi, const bf16x8& wlo, const bf16x8& bhi, const bf16x8& blo) {
@@ -1371,6 +1407,10 @@ __global__ __launch_bounds__(256, 1) void inr_refine_kernel(const InrArgs a) {
         };
 
         // ---- layer 0 -----------------------------------------------------------------------------------------
+        REF_STAMP(0);
+#ifdef MRIRT_REF_STAMPS
+        if (batchNo == 2u && lane == 0) reinterpret_cast<unsigned long long*>(a.logits)[((size_t)blockIdx.x * 4 + waveS) * 64 + 6] = __builtin_amdgcn_s_memtime();
+#endif
         {
             const uint32_t b0 = a.L.biasOff[0];
 #pragma unroll
@@ -1392,46 +1432,62 @@ __global__ __launch_bounds__(256, 1) void inr_refine_kernel(const InrArgs a) {
             }
         }
         // ---- hidden layers -----------------------------------------------------------------------------------
+        REF_STAMP(1);
         for (uint32_t l = 1; l + 1 < a.L.numLayers; ++l) {
 #pragma unroll
-            for (int t = 0; t < KT; ++t) { Hc_hi[t][0] = Hn_hi[t][0]; Hc_hi[t][1] = Hn_hi[t][1]; Hc_lo[t][0] = Hn_lo[t][0]; Hc_lo[t][1] = Hn_lo[t][1]; }
+            for (int t = 0; t < KT; ++t)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { Hc_hi[t][j] = Hn_hi[t][j]; Hc_lo[t][j] = Hn_lo[t][j]; }
             const uint32_t bl = a.L.biasOff[l];
             f32x16 accPrev;                              // finished tile o - 1: activated and split under tile o's MFMAs
+            f32x16 biasNext;                             // tile o + 1's biases (its initial accumulator), read under tile o's MFMAs
 #pragma unroll
             for (int o = 0; o < KT; ++o) {
-                issue_tile();
-                f32x16 acc = bias_tile(bl, o);
+                if (l == 2) REF_STAMP(8 + 3 * o);
+                issue_begin();
+                if (l == 2 && o == 2) REF_STAMP(40);
+                f32x16 acc = o == 0 ? bias_tile(bl, 0) : biasNext;
                 bf16x8 rhi[RD], rlo[RD];
 #pragma unroll
                 for (int d = 0; d < RD; ++d) if (d < NKH) { rhi[d] = frag_at(2 * d); rlo[d] = frag_at(2 * d + 1); }
 #pragma unroll
                 for (int q = 0; q < NKH; ++q) {
-                    mfma3(acc, rhi[q % RD], rlo[q % RD], Hc_hi[q >> 1][q & 1], Hc_lo[q >> 1][q & 1]);
+                    mfma3(acc, rhi[q % RD], rlo[q % RD], b_frag(Hc_hi[q >> 1], q & 1), b_frag(Hc_lo[q >> 1], q & 1));
+                    if (l == 2 && o == 2) REF_STAMP(41 + q);
                     if (q + RD < NKH) { rhi[q % RD] = frag_at(2 * (q + RD)); rlo[q % RD] = frag_at(2 * (q + RD) + 1); }
-                    if (o > 0) {
 #pragma unroll
-                        for (int i = q * 16 / NKH; i < (q + 1) * 16 / NKH; ++i) act_one(accPrev, o - 1, i);
+                    for (int i = q * PERW / NKH; i < (q + 1) * PERW / NKH; ++i) issue_part(i);      // the tile three ahead
+                    if (q == NKH / 2 && o + 1 < KT) biasNext = bias_tile(bl, o + 1);
+                    if (o > 0) {                     // the pairs complete by the end of this k step
+#pragma unroll
+                        for (int pr = (q * 16 / NKH) / 2; pr < ((q + 1) * 16 / NKH) / 2; ++pr) act_pair(accPrev, o - 1, 2 * pr);
                     }
                     __builtin_amdgcn_sched_barrier(0);   // keep the slices where they are written: one per k step
                 }
+                issue_end();
                 accPrev = acc;
+                if (l == 2) REF_STAMP(9 + 3 * o);
                 tile_done();
+                if (l == 2) REF_STAMP(10 + 3 * o);
             }
-#pragma unroll
-            for (int i = 0; i < 16; ++i) act_one(accPrev, KT - 1, i);     // the layer's last tile
+            activate(accPrev, KT - 1);                   // the layer's last tile
+            REF_STAMP(1 + l);
         }
         // ---- head ----------------------------------------------------------------------------------------------
         {
+            REF_STAMP(32);
             issue_tile();
+            REF_STAMP(33);
             f32x16 acc = bias_tile(a.L.biasOff[a.L.numLayers - 1], 0);
             bf16x8 rhi[RD], rlo[RD];
 #pragma unroll
             for (int d = 0; d < RD; ++d) if (d < NKH) { rhi[d] = frag_at(2 * d); rlo[d] = frag_at(2 * d + 1); }
 #pragma unroll
             for (int q = 0; q < NKH; ++q) {
-                mfma3(acc, rhi[q % RD], rlo[q % RD], Hn_hi[q >> 1][q & 1], Hn_lo[q >> 1][q & 1]);
+                mfma3(acc, rhi[q % RD], rlo[q % RD], b_frag(Hn_hi[q >> 1], q & 1), b_frag(Hn_lo[q >> 1], q & 1));
                 if (q + RD < NKH) { rhi[q % RD] = frag_at(2 * (q + RD)); rlo[q % RD] = frag_at(2 * (q + RD) + 1); }
             }
+            REF_STAMP(34);
             float best = -INFINITY, second = -INFINITY;
             uint32_t bestc = 4 * h;
 #pragma unroll
@@ -1442,8 +1498,15 @@ __global__ __launch_bounds__(256, 1) void inr_refine_kernel(const InrArgs a) {
             const float ob = __shfl_xor(best, 32);
             const uint32_t oc = __shfl_xor(bestc, 32);
             if (ob > best || (ob == best && oc < bestc)) { best = ob; bestc = oc; }
+            REF_STAMP(35);
             tile_done();                                 // (before the stores: they would count against the DMA budget)
+            REF_STAMP(5);
+            ++batchNo;
+#ifdef MRIRT_REF_STAMPS
+            if (false) {
+#else
             if (a.logits != nullptr && valid) {
+#endif
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const uint32_t cls = (i & 3) + 8 * (i >> 2) + 4 * h;
@@ -1457,7 +1520,7 @@ __global__ __launch_bounds__(256, 1) void inr_refine_kernel(const InrArgs a) {
     // ---- scan for marks, batch as they accumulate ------------------------------------------------------------
     uint32_t cnt = 0;                                    // replicated in every thread: entries waiting in `list`
     __syncthreads();
-    for (int64_t seg = blockIdx.x; seg * kSeg < nPts; seg += gridDim.x) {
+    for (int64_t seg = blockIdx.x; seg * kSeg < nPts; ) {
         const int64_t base = seg * kSeg;
         int16_t v[kScanU];
 #pragma unroll
@@ -1465,6 +1528,8 @@ __global__ __launch_bounds__(256, 1) void inr_refine_kernel(const InrArgs a) {
             const int64_t idx = base + u * 256 + threadIdx.x;
             v[u] = (!a.refineAll && idx < nPts) ? a.argmax[idx] : (int16_t)0;
         }
+        // the segment after this one: the next of the round-robin deal, or the next nobody has taken yet
+        if (a.segTicket != nullptr && threadIdx.x == 0) listCount[1] = atomicAdd(a.segTicket, 1u);
 #pragma unroll
         for (int u = 0; u < kScanU; ++u) {
             const int64_t idx = base + u * 256 + threadIdx.x;
@@ -1477,15 +1542,17 @@ __global__ __launch_bounds__(256, 1) void inr_refine_kernel(const InrArgs a) {
         }
         __syncthreads();
         cnt = *listCount;
-        const bool lastSeg = (seg + gridDim.x) * kSeg >= nPts;       // after the last segment the remainder goes as a short batch
+        const int64_t nextSeg = a.segTicket != nullptr ? (int64_t)gridDim.x + (int64_t)listCount[1] : seg + (int64_t)gridDim.x;
+        const bool lastSeg = nextSeg * kSeg >= nPts;                 // after the last segment the remainder goes as a short batch
         while (cnt >= (uint32_t)kBatch || (lastSeg && cnt > 0)) {    // (ONE call site: the batch body is inlined once)
             const uint32_t m = cnt < (uint32_t)kBatch ? cnt : (uint32_t)kBatch;
             run_batch(cnt - m, m);
             cnt -= m;
         }
-        __syncthreads();                                 // every wave has read its list entries
+        __syncthreads();                                 // every wave has read its list entries (and the next segment's number)
         if (threadIdx.x == 0) *listCount = cnt;
         __syncthreads();
+        seg = nextSeg;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the stream's look-ahead DMAs: nothing may be in flight at exit
 }
@@ -1614,7 +1681,7 @@ static int fill_args(const MrirtInrDesc* d, InrArgs& a) {
     a.coords = nullptr; a.feats = nullptr; a.n = 0; a.nDev = nullptr; a.volume = 0; a.H = a.W = a.D = 1;
     a.logits = nullptr; a.argmax = nullptr;
     a.tie = reinterpret_cast<const float*>(a.wpack + (size_t)tail_frag(a.L) * 64);     // written by mrirt_inr_pack_weights
-    a.tieScale = 0.0f; a.refineAll = 0;
+    a.tieScale = 0.0f; a.refineAll = 0; a.segTicket = nullptr;
     a.flags = d->flags; a.tieSigmas = d->tieSigmas;
     return MRIRT_OK;
 }
@@ -1622,12 +1689,12 @@ static int fill_args(const MrirtInrDesc* d, InrArgs& a) {
 // Internal (mrirt_host.h): the forward pass with the point count read from device memory — used by the
 // chunked C5 render (brats_march.hip), whose producer kernel sizes each chunk's batch on the device.
 int inr_forward_dev_n(const MrirtInrDesc* desc, const float* coords, const float* feats, int64_t nMax,
-                      const uint32_t* nDev, int16_t* argmax, hipStream_t s) {
+                      const uint32_t* nDev, int16_t* argmax, uint32_t* segTicket, hipStream_t s) {
     InrArgs a;
     int rc = fill_args(desc, a);
     if (rc != MRIRT_OK) return rc;
     if (desc->kind >= 2 || !coords || !feats || !argmax || !nDev) return MRIRT_ERR_ARG;
-    a.coords = coords; a.feats = feats; a.n = nMax; a.nDev = nDev; a.argmax = argmax;
+    a.coords = coords; a.feats = feats; a.n = nMax; a.nDev = nDev; a.argmax = argmax; a.segTicket = segTicket;
     return launch_inr(a, s);
 }
 
@@ -1735,8 +1802,9 @@ extern "C" int mrirt_inr_pack_weights(const MrirtInrDesc* desc, const float* w_f
     uint4* ref = static_cast<uint4*>(packed) + (size_t)ref_base_frag(L) * 64;
     hipLaunchKernelGGL(inr_pack_ref_kernel, dim3((L.refTotalFrags * 64 + 255) / 256), dim3(256), 0, s, w_f32, ref, L);
     MRIRT_HIP(hipGetLastError());
-    // the calibration record: zero (= nothing is marked) until the biases are known
-    MRIRT_HIP(hipMemsetAsync(static_cast<uint4*>(packed) + (size_t)tail_frag(L) * 64, 0, 1024, s));
+    // the slack after the refine image (DMA'd into ring slots nobody reads) and the calibration record: zero (= nothing is
+    // marked) until the biases are known
+    MRIRT_HIP(hipMemsetAsync(ref + (size_t)L.refTotalFrags * 64, 0, ((size_t)kRefSlackFrags + 1) * 1024, s));
     if (desc->weights == packed && desc->biases != nullptr) return calibrate(desc, s);
     return MRIRT_OK;
 }

@@ -203,8 +203,9 @@ inline void fill_label_addr(LabelAddr& a, const uint32_t dims[3], uint32_t layou
     }
 }
 
-// inr_mlp.hip: the MLP forward with the point count in device memory (argmax only)
+// inr_mlp.hip: the MLP forward with the point count in device memory (argmax only); segTicket: nullptr, or a zeroed device
+// word the near-tie refinement deals its segments with
 int inr_forward_dev_n(const MrirtInrDesc* desc, const float* coords, const float* feats, int64_t nMax,
-                      const uint32_t* nDev, int16_t* argmax, hipStream_t s);
+                      const uint32_t* nDev, int16_t* argmax, uint32_t* segTicket, hipStream_t s);
 
 }  // namespace mrirt

@@ -284,14 +284,21 @@ def render_brats_inr(params, intensities, net: PackedMLP, zmu, zsigma, labels=No
     alive (t < t1, T > 0.01) have their next samples classified ("all live sample points"); no host
     synchronisation inside the frame.  ``chunk_steps=None`` picks the pass length from the scene: where the intensity
     channel alone cannot take any ray to T <= ert (intensityAlpha x box diagonal <= -ln ert — the reference viewer's whole
-    slider range) no sample is classified in vain whatever the pass length, and 64-step passes are the
-    faster ones (fewer launches and refinement rounds: 9.6 against 10.1 ms per frame on the config-5 scene); otherwise 32
+    slider range) no sample is classified in vain whatever the pass length, and 96-step passes are the
+    fastest (fewer launches and refinement rounds: 10.13 / 9.88 / 9.68 / 9.72 / 9.76 ms per frame with 32 / 64 / 96 / 128 / 256
+    steps on the config-5 scene, round 4); otherwise 32
     (a terminating ray wastes at most 31 samples; 8.9 against 9.2 ms on the dense preset).  Any value gives the same bits.  ``one_pass=True`` is the three-pass form over whole rays (count every
     sample in [t0,t1) -> emit -> ONE batched forward -> composite with the class stream); both give the same
     bits, and ``return_aux`` of the one-pass form exposes the emitted inputs and classes for the layered tests.
     """
-    from .render import _alloc_out, _bind_brats
+    from .render import Grid, _alloc_out, _bind_brats
     dev = _require_gpu()
+    if isinstance(intensities, Grid):                    # one "mod4" grid (upload_mod4) carries all four modalities
+        if intensities.layout != "mod4":
+            raise ValueError("a single grid must be the 'mod4' grid of upload_mod4; per-modality grids go in a list of four")
+        if one_pass:
+            raise ValueError("the whole-ray three-pass form marches with the K1 kernels: bind per-modality grids")
+        intensities = [intensities] * 4
     if int(params["showPred"]) == 0:
         raise ValueError("render_brats_inr draws the prediction overlay: set gParams.showPred")
     if net.desc.kind not in (KIND_FOURIER_RELU, KIND_SIREN) or net.desc.numMods != 4:
@@ -310,7 +317,7 @@ def render_brats_inr(params, intensities, net: PackedMLP, zmu, zsigma, labels=No
     if chunk_steps is None:
         diag = float(np.sqrt(sum((float(P.voxelSize[k]) * int(P.dims[k])) ** 2 for k in range(3))))
         ert = float(E.ertThreshold) if int(E.ertOverride) else 0.01
-        chunk_steps = 64 if ert > 0.0 and float(P.intensityAlpha) * diag <= -np.log(ert) else 32
+        chunk_steps = 96 if ert > 0.0 and float(P.intensityAlpha) * diag <= -np.log(ert) else 32
     if not one_pass:
         nbytes = int(lib.mrirt_brats_inr_scratch_bytes(C.byref(P), int(chunk_steps)))
         if nbytes <= 0:

@@ -19,7 +19,7 @@ EXT_DEFAULTS: Dict[str, Any] = dict(
     ertThreshold=None,            # None -> the shader's hard-coded 0.01 (brats_rt.slang:117)
     math="strict",                # "strict" (bit-faithful) | "fast"
     outFormat="rgba32f",          # "rgba32f" | "rgba16f" (the reference's texture format)
-    layout="linear",              # intensity grids: "linear" | "brick" | "vg" | "quad" | "vga"
+    layout="linear",              # intensity grids: "linear" | "brick" | "vg" | "quad" | "vga" | "mod4" (render_brats_inr only)
     labelLayout="linear",         # labels / preds: "linear" | "brick" | "labcell" (both overlays per cell: upload_label_cells)
     tileSize=0, tileRank=0, tileWorld=0, tileSkew=0,
     kernelVariant=0,
@@ -28,7 +28,7 @@ EXT_DEFAULTS: Dict[str, Any] = dict(
 _MATH = {"strict": _lib.MATH_STRICT, "fast": _lib.MATH_FAST}
 _FMT = {"rgba32f": _lib.OUT_RGBA32F, "rgba16f": _lib.OUT_RGBA16F}
 _LAYOUT = {"linear": _lib.LAYOUT_LINEAR, "brick": _lib.LAYOUT_BRICK, "vg": _lib.LAYOUT_VG, "quad": _lib.LAYOUT_QUAD,
-           "vga": _lib.LAYOUT_VGA, "labcell": _lib.LAYOUT_LABCELL}
+           "vga": _lib.LAYOUT_VGA, "labcell": _lib.LAYOUT_LABCELL, "mod4": _lib.LAYOUT_MOD4}
 
 _BRATS_REQUIRED = ("imageSize", "fovY", "eye", "U", "V", "W", "volMin", "voxelSize", "dims", "stepSize",
                    "nearT", "farT", "bgColor", "volEnabled", "volWeight", "ww", "wl", "intensityAlpha",

@@ -154,14 +154,14 @@ def test_c5_chunked_is_bit_identical_to_one_pass(setup, kind):
         assert a["live_samples"] == a0["live_samples"]
         assert a0["live_samples"] <= a["queries"] <= a0["queries"]
         seen.add(a["queries"])
-    # the default pass length follows the scene: 32 where intensity alone can terminate a ray (this dense preset), 64 where it
+    # the default pass length follows the scene: 32 where intensity alone can terminate a ray (this dense preset), 96 where it
     # cannot (the reference viewer's slider range) — same bits either way
     img, a = inr.render_brats_inr(p, grids, net, s["zmu"], s["zsg"], labels=gl, return_aux=True)
     assert a["chunk_steps"] == 32 and torch.equal(img, ref)
     thin = dict(p, intensityAlpha=0.4)
     ref_thin = inr.render_brats_inr(thin, grids, net, s["zmu"], s["zsg"], labels=gl, one_pass=True)
     img, a = inr.render_brats_inr(thin, grids, net, s["zmu"], s["zsg"], labels=gl, return_aux=True)
-    assert a["chunk_steps"] == 64 and torch.equal(img, ref_thin)
+    assert a["chunk_steps"] == 96 and torch.equal(img, ref_thin)
     img1, a1 = inr.render_brats_inr(p, grids, net, s["zmu"], s["zsg"], labels=gl, return_aux=True, chunk_steps=1)
     assert a1["queries"] == a0["live_samples"], "one step per pass classifies exactly the live samples"
     assert len(seen) > 1
@@ -183,6 +183,20 @@ def test_c5_chunked_is_bit_identical_to_one_pass(setup, kind):
         assert a["live_samples"] == ash["live_samples"] and a["shaded_samples"] == ash["shaded_samples"]
     br = [mrirt.upload_grid(v, dims, "brick") for v in s["vols"]]
     assert torch.equal(inr.render_brats_inr(p, br, net, s["zmu"], s["zsg"], labels=gl, chunk_steps=7), ref)
+    # the four modalities as ONE float4 grid (MRIRT_LAYOUT_MOD4): same bits, same counters, at every pass length
+    m4 = mrirt.upload_mod4(s["vols"], dims)
+    for chunk in (5, 32, None):
+        img, a = inr.render_brats_inr(p, m4, net, s["zmu"], s["zsg"], labels=gl, return_aux=True, chunk_steps=chunk)
+        assert torch.equal(img, ref), chunk
+        assert a["live_samples"] == a0["live_samples"]
+    assert torch.equal(inr.render_brats_inr(dict(p, volEnabled=(0, 1, 0, 1)), m4, net, s["zmu"], s["zsg"], labels=gl),
+                       inr.render_brats_inr(dict(p, volEnabled=(0, 1, 0, 1)), grids, net, s["zmu"], s["zsg"], labels=gl))
+    with pytest.raises(ValueError):                      # the whole-ray form marches with the K1 kernels
+        inr.render_brats_inr(p, m4, net, s["zmu"], s["zsg"], labels=gl, one_pass=True)
+    with pytest.raises(RuntimeError):                    # no gradients in it: MRIRT_ERR_LAYOUT
+        inr.render_brats_inr(p, m4, net, s["zmu"], s["zsg"], labels=gl, ext=dict(synth.SHADE_EXT, layout="mod4"))
+    with pytest.raises(RuntimeError):                    # and no K1 entry point takes it
+        mrirt.render_brats(dict(p, showPred=0), [m4] * 4, labels=gl)
     # no seg overlay bound at all (the emission then records no seg labels)
     p3 = dict(p, showSeg=0)
     ref3 = inr.render_brats_inr(p3, grids, net, s["zmu"], s["zsg"], labels=None, one_pass=True)

@@ -22,7 +22,7 @@ def test_header_symbols_are_exported():
     lib = _lib.lib()                       # dlopen works without a GPU; no kernel is launched here
     for s in declared:
         assert hasattr(lib, s), s
-    assert lib.mrirt_abi_version() == _lib.ABI_VERSION == 3
+    assert lib.mrirt_abi_version() == _lib.ABI_VERSION == 4
     assert lib.mrirt_status_string(0) == b"ok" and b"NULL" in lib.mrirt_status_string(-1)
 
 

@@ -17,7 +17,8 @@ from mrirt import inr, synth  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--nets", default="siren,fourier")
-ap.add_argument("--chunks", default="32,64,0")
+ap.add_argument("--chunks", default="32,96,0")
+ap.add_argument("--layout", default="mod4", choices=["mod4", "quad"], help="one float4 grid of all four modalities, or four quad grids")
 ap.add_argument("--alpha", type=float, default=0.4)
 ap.add_argument("--frames", type=int, default=5)
 a = ap.parse_args()
@@ -28,7 +29,8 @@ lab = synth.synth_labels(n)
 zmu = [float(v[v != 0].mean()) for v in vols]
 zsg = [float(v[v != 0].std() + 1e-6) for v in vols]
 p5 = synth.brats_scene(n, image, steps, channels=4, show_seg=True, show_pred=True, intensity_alpha=a.alpha)
-gv = [mrirt.upload_grid(v, (n, n, n), "quad") for v in vols]
+gq = [mrirt.upload_grid(v, (n, n, n), "quad") for v in vols]
+gm = mrirt.upload_mod4(vols, (n, n, n))
 gl = mrirt.upload_grid(lab, (n, n, n), "brick")
 rng = np.random.default_rng(0)
 for name in a.nets.split(","):
@@ -46,6 +48,7 @@ for name in a.nets.split(","):
     flop = 2 * sum(dims[i] * dims[i + 1] for i in range(5))
     for chunk in [int(c) for c in a.chunks.split(",")]:
         kw = dict(one_pass=True) if chunk == 0 else dict(chunk_steps=chunk)
+        gv = gq if (chunk == 0 or a.layout == "quad") else gm            # (the whole-ray form marches with the K1 kernels: quad grids)
         _, aux = inr.render_brats_inr(p5, gv, net, zmu, zsg, labels=gl, return_aux=True, **kw)
         ts = []
         for _ in range(a.frames):
@@ -53,6 +56,6 @@ for name in a.nets.split(","):
             e0.record(); inr.render_brats_inr(p5, gv, net, zmu, zsg, labels=gl, **kw); e1.record()
             torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
         ms = float(np.median(ts))
-        print(f"C5 {name:8s} {dims[0]}-4x256-4 chunk {chunk or 'whole-ray':>9}: {ms:7.3f} ms/frame, queries {aux['queries'] / 1e6:6.2f} M, "
+        print(f"C5 {name:8s} {dims[0]}-4x256-4 {'quad' if gv is gq else 'mod4'} chunk {chunk or 'whole-ray':>9}: {ms:7.3f} ms/frame, queries {aux['queries'] / 1e6:6.2f} M, "
               f"live {aux['live_samples'] / 1e6:6.2f} M, {aux['queries'] * flop / ms / 1e9:6.0f} TFLOP/s issued, "
               f"{aux['live_samples'] * flop / ms / 1e9:6.0f} TFLOP/s useful", flush=True)
