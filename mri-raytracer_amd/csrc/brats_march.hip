@@ -24,6 +24,7 @@
 // Template axes: STRICT (bit-faithful to the oracle / FAST: FMA + hardware exp2, rcp), LAYOUT
 // (0 linear, 1 4x4x2 fp32 bricks, 2 VG, 3 QUAD), SHADE (lattice-gradient Blinn-Phong extension); the
 // pipelined kernel adds NCH (modalities), GAMMA1, LABELS, SKIP (exact empty-space skipping).
+#include <type_traits>
 #include "brats_device.h"
 
 namespace mrirt {
@@ -161,8 +162,14 @@ struct MapWindow {
 // the skipping and generic kernels take the same grid through fetch_labels at run time).
 template <int LAYOUT, bool SHADE, int NCH, bool LABELS, bool SKIP, bool CELLS = false>
 struct Stage {
+    // MOD4: ONE tap set — the VG grid's eight float4 corners carry all four modalities (which of them are enabled is a run-time
+    // property of the frame: a.enabled[], one kernel whatever the viewer's check boxes say; NCH is not used)
+    static constexpr bool kMod4 = LAYOUT == MRIRT_LAYOUT_MOD4;
+    static_assert(!(kMod4 && SHADE), "MOD4 grids carry no gradients");
+    using TapSet = typename std::conditional<kMod4, Taps<2, true>, Taps<kMod4 ? 2 : LAYOUT, SHADE>>::type;
+    static constexpr int kSets = kMod4 ? 1 : NCH;
     Cell s;
-    Taps<LAYOUT, SHADE> taps[NCH];
+    TapSet taps[kSets];
     Labels lb;
     u32x2 cw;                        // CELLS: the cell's two label words, in flight with the taps
     uint32_t csh;                    // ... and which nibble of them is this sample's
@@ -173,17 +180,21 @@ struct Stage {
     // loads into a divergent branch, and a load the compiler cannot count past turns every vmcnt of the loop into 0 — for the
     // plain kernels too.  mrirt_render_brats_stream takes the generic kernel.)
     // ---- the asynchronous form (plain pipelined kernels: !SKIP): gathers the compiler does not count, one explicit wait ----
-    static constexpr int kTapLoads = NCH * (LAYOUT == 3 ? 2 : LAYOUT == 0 ? 4 : 8);
+    static constexpr int kTapLoads = kSets * (LAYOUT == 3 ? 2 : LAYOUT == 0 ? 4 : 8);
     static constexpr int kLoads = kTapLoads + (LABELS ? (CELLS ? 1 : 2) : 0);   // vector-memory instructions issue_async() emits
     __device__ __forceinline__ void issue_async(const K1Args& a, const WaveGrid<LAYOUT>& wg) {
         CellOffsets k;
         if constexpr (LAYOUT == 4) k = flat_cell(wg.f, s.ix, s.iy, s.iz);
         else if constexpr (LAYOUT == 0) { k.o = s.ix + s.iy * wg.g->sY + s.iz * wg.g->sZ; k.dx = 1u; k.dy = wg.g->sY; k.dz = wg.g->sZ; }
         else k = vec4_cell(*wg.g, s.ix, s.iy, s.iz);
+        if constexpr (kMod4) {
+            taps[0].issue_async(wg.base(a.vol[0]), k);
+        } else {
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) taps[c].issue_async(wg.base(a.vol[a.chan[c]]), k);
+            for (int c = 0; c < NCH; ++c) taps[c].issue_async(wg.base(a.vol[a.chan[c]]), k);
+        }
         if constexpr (LABELS && CELLS) {
-            static_assert(LAYOUT == 3, "label cells are stored in the QUAD grid's element order");
+            static_assert(LAYOUT == 3 || kMod4, "label cells are stored in the QUAD (= VG = MOD4) grid's element order");
             async_load_words2(cw, a.labCell, k.o << 3);
             csh = label_corner_shift(a, s);
         } else if constexpr (LABELS) {
@@ -233,7 +244,7 @@ struct Stage {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) taps[c].p[i] = q[4 * c + i];
         } else {
-            static_assert(LAYOUT == 3 || NCH == 1, "VG / VGA stages hold one modality");
+            static_assert(LAYOUT == 3 || NCH == 1 || kMod4, "VG / VGA stages hold one modality");
             taps[0].template arrive<YOUNGER>();
         }
         if constexpr (LABELS && CELLS) {
@@ -255,7 +266,7 @@ struct Stage {
         Cell c0 = s;
         if (SKIP && empty) { c0.ix = 0u; c0.iy = 0u; c0.iz = 0u; }
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) taps[c].template issue<false>(wg.base(a.vol[a.chan[c]]), wg.dims(), c0);   // grid (copy) < 4 GiB (launch())
+        for (int c = 0; c < kSets; ++c) taps[c].template issue<false>(wg.base(a.vol[kMod4 ? 0 : a.chan[c]]), wg.dims(), c0);   // grid (copy) < 4 GiB (launch())
         if constexpr (LABELS) fetch_labels(a, s, lb);
     }
     template <bool STRICT, bool GAMMA1>
@@ -267,6 +278,14 @@ struct Stage {
             return;
         }
         float v = 0.0f, g[3] = { 0.0f, 0.0f, 0.0f };
+        if constexpr (kMod4) {
+            // the shader's modality loop (brats_rt.slang:121-130) over the four components, ascending, enabled ones only
+            float sv[4], rest[3];
+            taps[0].template eval<STRICT>(s, sv[0], rest);
+            sv[1] = rest[0]; sv[2] = rest[1]; sv[3] = rest[2];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) if (a.enabled[m] != 0) v = Mm::mad(sv[m], a.weight[m], v);       // uniform branches
+        } else
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {                      // ascending modality order, as the shader
             float sv, gm[3];
@@ -613,13 +632,13 @@ static int launch_pipe(const K1Args& a, hipStream_t s) {
     // (LINEAR grids have no skipping kernels: mrirt_render_brats_skip never builds a map for them)
     constexpr bool kHasSkip = LAYOUT != 0;
     const bool skip = kHasSkip && a.skipDist != nullptr;
-    const bool cellsKernel = LAYOUT == 3 && a.labCell != nullptr && overlays && !skip;      // label cells: the plain pipelined kernel with one label gather
+    const bool cellsKernel = (LAYOUT == 3 || LAYOUT == MRIRT_LAYOUT_MOD4) && a.labCell != nullptr && overlays && !skip;      // label cells: the plain pipelined kernel with one label gather
     const bool skipKernel = skip && (!STRICT || a.gamma == 1.0f);
     if (g_family_probe != nullptr) {
         *g_family_probe = MRIRT_KERNEL_PIPELINED | (skipKernel ? MRIRT_KERNEL_SKIPPING : 0) | (cellsKernel ? MRIRT_KERNEL_LABEL_CELLS : 0);
         return MRIRT_OK;
     }
-    if constexpr (LAYOUT == 3) {
+    if constexpr (LAYOUT == 3 || LAYOUT == MRIRT_LAYOUT_MOD4) {
         if (cellsKernel) {
             if (STRICT && a.gamma == 1.0f) hipLaunchKernelGGL((brats_march_pipe_kernel<STRICT, LAYOUT, SHADE, NCH, STRICT, true, false, true>), grid, block, 0, s, a);
             else                           hipLaunchKernelGGL((brats_march_pipe_kernel<STRICT, LAYOUT, SHADE, NCH, false, true, false, true>), grid, block, 0, s, a);
@@ -698,11 +717,18 @@ static int launch(const K1Args& a, bool pipeAsked, hipStream_t s) {
             }
         }
     }
-    if (g_family_probe != nullptr) { *g_family_probe = MRIRT_KERNEL_GENERIC; return MRIRT_OK; }
-    const dim3 grid(a.map.chunk * kXcds), block(a.map.blockPx == 8 ? 64 : 256);
-    hipLaunchKernelGGL((brats_march_kernel<STRICT, LAYOUT, SHADE>), grid, block, 0, s, a);
-    MRIRT_HIP(hipGetLastError());
-    return MRIRT_OK;
+    if constexpr (LAYOUT == MRIRT_LAYOUT_MOD4) {      // MOD4: the pipelined kernel or nothing (grids < 4 GiB, label grids < 2^30 elements)
+        (void)pipe;
+        const bool labelsFit = !((a.showSeg != 0 || a.showPred != 0) && labelElems >= (1ull << 30));
+        if (!a.grid.wide && labelsFit && a.classStream == nullptr) return launch_pipe<STRICT, MRIRT_LAYOUT_MOD4, false, 4>(a, s);
+        return MRIRT_ERR_LAYOUT;
+    } else {
+        if (g_family_probe != nullptr) { *g_family_probe = MRIRT_KERNEL_GENERIC; return MRIRT_OK; }
+        const dim3 grid(a.map.chunk * kXcds), block(a.map.blockPx == 8 ? 64 : 256);
+        hipLaunchKernelGGL((brats_march_kernel<STRICT, LAYOUT, SHADE>), grid, block, 0, s, a);
+        MRIRT_HIP(hipGetLastError());
+        return MRIRT_OK;
+    }
 }
 
 template <bool STRICT>
@@ -713,6 +739,7 @@ static int launch_layout(const K1Args& a, uint32_t layout, bool shade, bool pipe
         case MRIRT_LAYOUT_VG:     return shade ? launch<STRICT, 2, true>(a, pipe, s) : launch<STRICT, 2, false>(a, pipe, s);
         case MRIRT_LAYOUT_QUAD:   return shade ? (int)MRIRT_ERR_LAYOUT : launch<STRICT, 3, false>(a, pipe, s);
         case MRIRT_LAYOUT_VGA:    return shade ? launch<STRICT, 4, true>(a, pipe, s) : launch<STRICT, 4, false>(a, pipe, s);
+        case MRIRT_LAYOUT_MOD4:   return shade ? (int)MRIRT_ERR_LAYOUT : launch<STRICT, MRIRT_LAYOUT_MOD4, false>(a, pipe, s);
         default: return MRIRT_ERR_LAYOUT;
     }
 }
@@ -1008,7 +1035,7 @@ struct Prepared { uint32_t layout, math; bool shade, pipe, slab, ring; };
 // validate + fill the kernel arguments shared by every K1 entry point
 static int prepare(const MrirtBratsParams* p, const MrirtRenderExt* ext, const void* const vol[4],
                    const void* labels, const void* preds, bool needVolumes, int64_t pitch_px,
-                   K1Args& a, Prepared& cfg, bool allowMod4 = false) {
+                   K1Args& a, Prepared& cfg) {
     if (!p || (needVolumes && !vol)) return MRIRT_ERR_NULL;
     for (int k = 0; k < 3; ++k) if (p->dims[k] < 2) return MRIRT_ERR_DIMS;
     const uint32_t layout = ext ? ext->layout : (uint32_t)MRIRT_LAYOUT_LINEAR;
@@ -1017,10 +1044,10 @@ static int prepare(const MrirtBratsParams* p, const MrirtRenderExt* ext, const v
     const uint32_t fmt = ext ? ext->outFormat : (uint32_t)MRIRT_OUT_RGBA32F;
     const uint32_t variant = ext ? ext->kernelVariant : 0u;
     const bool labCells = labLayout == MRIRT_LAYOUT_LABCELL;              // both overlays' corner labels per cell: QUAD grids only
-    const bool mod4 = layout == MRIRT_LAYOUT_MOD4 && allowMod4;          // all four modalities in one float4 grid: mrirt_render_brats_inr only
+    const bool mod4 = layout == MRIRT_LAYOUT_MOD4;                       // all four modalities in one float4 grid (vol[0])
     if ((layout > MRIRT_LAYOUT_VGA && !mod4) || (labLayout > MRIRT_LAYOUT_BRICK && !labCells) || math > MRIRT_MATH_FAST || fmt > MRIRT_OUT_RGBA16F)
         return MRIRT_ERR_LAYOUT;
-    if (labCells && layout != MRIRT_LAYOUT_QUAD) return MRIRT_ERR_LAYOUT;
+    if (labCells && layout != MRIRT_LAYOUT_QUAD && !mod4) return MRIRT_ERR_LAYOUT;
     if (labCells && mrirt_vec4_elems(p->dims) >= (int64_t)1 << 29) return MRIRT_ERR_DIMS;      // 32-bit byte offsets of 8-byte elements
     if (layout == MRIRT_LAYOUT_VGA)
         for (int c = 0; c < 3; ++c) if (vga_copy_elems(p->dims, c) >= (1ull << 28)) return MRIRT_ERR_DIMS;   // 32-bit byte offsets per copy
@@ -1257,7 +1284,7 @@ static bool skip_applicable(const MrirtBratsParams* p, const K1Args& a, const Pr
     const bool wide = a.grid.wide != 0;
     const bool overlays = p->showSeg != 0 || p->showPred != 0;
     const bool layoutOk = ((cfg.layout == MRIRT_LAYOUT_VG && !wide) || cfg.layout == MRIRT_LAYOUT_VGA) ? (a.nch == 1 || !overlays)   // pipelined / rolling
-                        : (cfg.layout == MRIRT_LAYOUT_QUAD && !wide && !cfg.shade);
+                        : ((cfg.layout == MRIRT_LAYOUT_QUAD || cfg.layout == MRIRT_LAYOUT_MOD4) && !wide && !cfg.shade);
     const bool mathOk = cfg.math == MRIRT_MATH_FAST || p->gamma == 1.0f;
     ok = ok && cfg.pipe && !cfg.slab && !cfg.ring && layoutOk && mathOk;
     for (int k = 0; k < 3; ++k) ok = ok && (p->dims[k] + 7) / 8 <= 256;   // macro coordinates travel through 8-bit wave reductions
@@ -1390,12 +1417,13 @@ extern "C" int mrirt_brats_sample_counts(const MrirtBratsParams* p, const MrirtR
 
 template <bool STRICT>
 static int launch_emit(const K1Args& a, const EmitArgs& e, uint32_t layout, hipStream_t s) {
-    if (layout > MRIRT_LAYOUT_QUAD) return MRIRT_ERR_LAYOUT;          // the C5 passes read LINEAR / BRICK / VG / QUAD grids
+    if (layout > MRIRT_LAYOUT_QUAD && layout != MRIRT_LAYOUT_MOD4) return MRIRT_ERR_LAYOUT;      // the C5 passes read LINEAR / BRICK / VG / QUAD / MOD4 grids
     const dim3 grid(a.map.chunk * kXcds), block(a.map.blockPx == 8 ? 64 : 256);
     switch (layout) {
         case MRIRT_LAYOUT_LINEAR: hipLaunchKernelGGL((emit_samples_kernel<STRICT, 0>), grid, block, 0, s, a, e); break;
         case MRIRT_LAYOUT_BRICK:  hipLaunchKernelGGL((emit_samples_kernel<STRICT, 1>), grid, block, 0, s, a, e); break;
         case MRIRT_LAYOUT_VG:     hipLaunchKernelGGL((emit_samples_kernel<STRICT, 2>), grid, block, 0, s, a, e); break;
+        case MRIRT_LAYOUT_MOD4:   hipLaunchKernelGGL((emit_samples_kernel<STRICT, MRIRT_LAYOUT_MOD4>), grid, block, 0, s, a, e); break;
         default:                  hipLaunchKernelGGL((emit_samples_kernel<STRICT, 3>), grid, block, 0, s, a, e); break;
     }
     MRIRT_HIP(hipGetLastError());
@@ -1515,7 +1543,7 @@ extern "C" int mrirt_render_brats_inr(const MrirtBratsParams* p, const MrirtRend
     if ((net->kind != MRIRT_INR_FOURIER_RELU && net->kind != MRIRT_INR_SIREN) || net->numMods != 4) return MRIRT_ERR_ARG;
     K1Args a;
     Prepared cfg;
-    int rc = prepare(p, ext, vol, labels, nullptr, true, pitch_px, a, cfg, true);
+    int rc = prepare(p, ext, vol, labels, nullptr, true, pitch_px, a, cfg);
     if (rc != MRIRT_OK) return rc;
     if (a.labCell != nullptr) return MRIRT_ERR_LAYOUT;           // the C5 passes read the ground-truth grid themselves (LINEAR / BRICK)
     if (p->showPred == 0) return MRIRT_ERR_ARG;

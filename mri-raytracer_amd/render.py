@@ -67,10 +67,11 @@ class Grid:
     ``device.create_buffer`` + ``copy_from_numpy`` (inr/viewer/brats_viewer.py:219-230)."""
     data: torch.Tensor            # 1-D, device
     dims: Tuple[int, int, int]    # (X, Y, Z), x fastest in the linear layout
-    layout: str = "linear"        # "linear" | "brick" | "vg" | "quad" | "vga"
+    layout: str = "linear"        # "linear" | "brick" | "vg" | "quad" | "vga" | "mod4" | "labcell"
     macro: Optional[torch.Tensor] = None   # per 8^3 macro cell: fp32 upper bound (intensities) / any-label word
                                            # (label grids) — what exact empty-space skipping tests (skip=True)
     macro2: Optional[torch.Tensor] = None  # "labcell" grids: the prediction grid's summary (macro = the ground truth's)
+    macros: Optional[Tuple[Optional[torch.Tensor], ...]] = None   # "mod4" grids: the four modalities' summaries (or None each)
 
     @property
     def nbytes(self) -> int:
@@ -133,26 +134,35 @@ def upload_grid(linear: ArrayLike, dims: Sequence[int], layout: str = "brick", s
     return Grid(out, dims, "brick", macro)
 
 
-def upload_mod4(modalities: Sequence[ArrayLike], dims: Sequence[int], stream=None) -> Grid:
+def upload_mod4(modalities: Sequence[Optional[ArrayLike]], dims: Sequence[int], stream=None, macro: bool = True) -> Grid:
     """The four modalities of one case (linear fp32 grids, gIntensity0..3) as ONE "mod4" grid: float4 (m0, m1, m2, m3) per voxel
-    in the "vg" grid's element order (include/mrirt.h, MRIRT_LAYOUT_MOD4).  ``render_brats_inr`` reads all four modalities at
-    every sample; from this grid that is the same eight 16-byte gathers as from four "quad" grids, out of a quarter of the
-    memory (one set of cache lines per sample instead of four) — same bits.  Pass it as ``intensities``."""
+    in the "vg" grid's element order (include/mrirt.h, MRIRT_LAYOUT_MOD4).  An unshaded sample of a four-modality frame is the
+    same eight 16-byte gathers as from four "quad" grids, out of a quarter of the memory (one set of cache lines per sample
+    instead of four: config 2 0.40 -> 0.24 ms) — same bits.  Bind it four times (``[g] * 4``) to ``render_brats`` or pass it as
+    ``intensities`` to ``render_brats_inr``; which modalities are drawn stays ``gParams.volEnabled``.  A modality given as
+    ``None`` (one the frame never enables: the viewer binds a dummy buffer for it) is stored as zeros.  ``macro`` also builds
+    the per-modality 8^3 summaries that ``skip=True`` needs."""
     dev = _require_gpu()
     dims = tuple(int(v) for v in dims)
     if len(modalities) != 4:
         raise ValueError("upload_mod4 takes the four modalities of a case")
     with _on_stream(stream):                             # the linear copies are temporaries of the launch stream
-        ts = []
+        ts, macros, zeros = [], [], None
         for m, v in enumerate(modalities):
+            if v is None:
+                if zeros is None:
+                    zeros = torch.zeros(dims[0] * dims[1] * dims[2], dtype=torch.float32, device=dev)
+                ts.append(zeros); macros.append(None)
+                continue
             t = torch.as_tensor(v).reshape(-1).to(torch.float32).to(dev).contiguous()
             if t.numel() != dims[0] * dims[1] * dims[2]:
                 raise ValueError(f"modality {m} has {t.numel()} voxels, dims {dims} need {dims[0] * dims[1] * dims[2]}")
             ts.append(t)
+            macros.append(_build_macro(t, dims, stream) if macro else None)
         out = torch.empty(4 * vec4_elems(dims), dtype=torch.float32, device=dev)
         ptrs = (C.c_void_p * 4)(*[C.c_void_p(t.data_ptr()) for t in ts])
         _lib.check(_lib.lib().mrirt_build_mod4_grid(ptrs, _ptr(out), (C.c_uint32 * 3)(*dims), _stream_ptr(stream)), "mrirt_build_mod4_grid")
-    return Grid(out, dims, "mod4", None)
+    return Grid(out, dims, "mod4", None, None, tuple(macros))
 
 
 def upload_label_cells(seg: Optional[ArrayLike], pred: Optional[ArrayLike], dims: Sequence[int], stream=None, macro: bool = True) -> Grid:
@@ -269,8 +279,8 @@ def _bind_brats(params, intensities, labels, preds, ext, dev, pred_stream: bool 
     nvox = dims[0] * dims[1] * dims[2]
     need = {"linear": nvox, "brick": brick_elems(dims), "vg": 4 * vec4_elems(dims), "quad": 4 * vec4_elems(dims),
             "vga": 4 * vga_elems(dims), "labcell": 2 * vec4_elems(dims), "mod4": 4 * vec4_elems(dims)}
-    if lab_lay == "labcell" and lay != "quad":
-        raise ValueError("label cells (upload_label_cells) go with 'quad' intensity grids")
+    if lab_lay == "labcell" and lay not in ("quad", "mod4"):
+        raise ValueError("label cells (upload_label_cells) go with 'quad' or 'mod4' intensity grids")
     vols = []
     for m in range(4):
         v = intensities[m] if m < len(intensities) else None
@@ -367,10 +377,11 @@ def _bind_skip(P, E, vp, lab, prd, intensities, labels, preds, dev, stream):
     for m in range(4):
         g = intensities[m] if m < len(intensities) else None
         if P.volEnabled[m] != 0:
-            if not isinstance(g, Grid) or g.macro is None or g.macro.dtype != torch.float32:
-                raise ValueError(f"skip=True: gIntensity{m} must be a Grid made by upload_grid (it carries the macro-cell bounds)")
-            S.macroUb[m] = g.macro.data_ptr()
-            hold.append(g.macro)
+            mac = (g.macros[m] if g.macros is not None else None) if isinstance(g, Grid) and g.layout == "mod4" else getattr(g, "macro", None)
+            if not isinstance(g, Grid) or mac is None or mac.dtype != torch.float32:
+                raise ValueError(f"skip=True: gIntensity{m} must be a Grid made by upload_grid / upload_mod4 (it carries the macro-cell bounds)")
+            S.macroUb[m] = mac.data_ptr()
+            hold.append(mac)
     cells_grid = isinstance(labels, Grid) and labels.layout == "labcell"      # one grid carries both summaries
     for name, g, flag, which in (("macroSeg", labels, P.showSeg, "macro"),
                                  ("macroPred", labels if cells_grid else preds, P.showPred, "macro2" if cells_grid else "macro")):

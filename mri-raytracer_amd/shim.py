@@ -155,6 +155,19 @@ class ComputeKernel:
             hit = cache[key] = (g, seg, pred)
         return hit[0]
 
+    def _mod4(self, bufs: Sequence[Optional[Buffer]], dims) -> "_r.Grid":
+        """The enabled intensity buffers as ONE float4 grid (render.upload_mod4; a disabled modality is stored as zeros),
+        cached until one of them is rewritten."""
+        key = (dims,) + tuple((id(b), b._version) if b is not None else (0, 0) for b in bufs)
+        cache = self.device._mod4
+        hit = cache.get(key)
+        if hit is None:
+            n = dims[0] * dims[1] * dims[2]
+            g = _r.upload_mod4([b.tensor[:n] if b is not None else None for b in bufs], dims)
+            cache.clear()                                   # one case at a time; the entry keeps its buffers alive
+            hit = cache[key] = (g, tuple(bufs))
+        return hit[0]
+
     def _buf(self, b, dims, layout):
         if isinstance(b, Buffer):
             return b.grid(dims, layout)
@@ -178,19 +191,28 @@ class ComputeKernel:
         llay = "linear" if layout == "linear" else "brick"
         # dummy 1-element buffers stand in for disabled inputs (brats_viewer.py:247-248,437-438)
         en = [int(v) != 0 for v in p["volEnabled"]] + [int(p["showSeg"]) != 0, int(p["showPred"]) != 0]
+        nvox = dims[0] * dims[1] * dims[2]
+        # "auto", unshaded, two or more modalities: ONE float4 grid of the enabled modalities (MRIRT_LAYOUT_MOD4) instead of a
+        # quad grid each — the same gathers per sample out of a quarter of the memory (the viewer's four-modality frame)
+        if layout == "auto" and vlay == "quad" and sum(en[:4]) >= 2 and all((not on) or (b.tensor is not None and b.tensor.numel() >= nvox)
+                                                                            for b, on in zip(raw[:4], en[:4])):
+            vlay = "mod4"
         lays = [vlay] * 4 + [llay] * 2
-        bound = [self._buf(b, dims, lay) if on else None for b, on, lay in zip(raw, en, lays)]
+        if vlay == "mod4":
+            m4 = self._mod4([b if on else None for b, on in zip(raw[:4], en[:4])], tuple(dims))
+            bound = [m4] * 4 + [self._buf(b, dims, lay) if on else None for b, on, lay in zip(raw[4:], en[4:], lays[4:])]
+        else:
+            bound = [self._buf(b, dims, lay) if on else None for b, on, lay in zip(raw, en, lays)]
         # QUAD voxels + overlays: both label buffers as ONE cell-packed grid (render.upload_label_cells): a sample then takes one
         # 8-byte gather at its cell's own offset instead of two nearest-voxel gathers (same bits; the viewer's frame -10 %)
-        nvox = dims[0] * dims[1] * dims[2]
-        if vlay == "quad" and (en[4] or en[5]) and all((not on) or (b.tensor is not None and b.tensor.numel() >= nvox)
+        if vlay in ("quad", "mod4") and (en[4] or en[5]) and all((not on) or (b.tensor is not None and b.tensor.numel() >= nvox)
                                                        for b, on in zip(raw[4:], en[4:])):
             bound[4], bound[5] = self._label_cells(raw[4] if en[4] else None, raw[5] if en[5] else None, tuple(dims)), None
             llay = "labcell"
         e["layout"], e["labelLayout"] = vlay, llay
         # exact empty-space skipping rides on the macro-cell summaries upload_grid attached to the cached grids
-        skip = (self.device.skip_empty and vlay in ("vg", "vga", "quad")
-                and all(b is None or (isinstance(b, _r.Grid) and b.macro is not None) for b in bound))
+        skip = (self.device.skip_empty and vlay in ("vg", "vga", "quad", "mod4")
+                and all(b is None or (isinstance(b, _r.Grid) and (b.macro is not None or b.macros is not None)) for b in bound))
         _r.render_brats(p, bound[:4], bound[4], bound[5], out=tex.tensor, ext=e, skip=skip)
 
     def _volume(self, tc, vars, ext):
@@ -233,6 +255,7 @@ class Device:
         self.default_ext = {"layout": layout, "math": math}
         self.skip_empty = bool(skip_empty)
         self._label_cells: Dict[tuple, tuple] = {}          # the cell-packed copy of the bound (gLabels, gPreds) pair
+        self._mod4: Dict[tuple, tuple] = {}                 # the interleaved copy of the bound intensity buffers
 
     def load_program(self, path: Union[str, pathlib.Path], entry_points: Sequence[str]) -> Program:
         for ep in entry_points:

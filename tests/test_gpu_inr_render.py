@@ -195,8 +195,7 @@ def test_c5_chunked_is_bit_identical_to_one_pass(setup, kind):
         inr.render_brats_inr(p, m4, net, s["zmu"], s["zsg"], labels=gl, one_pass=True)
     with pytest.raises(RuntimeError):                    # no gradients in it: MRIRT_ERR_LAYOUT
         inr.render_brats_inr(p, m4, net, s["zmu"], s["zsg"], labels=gl, ext=dict(synth.SHADE_EXT, layout="mod4"))
-    with pytest.raises(RuntimeError):                    # and no K1 entry point takes it
-        mrirt.render_brats(dict(p, showPred=0), [m4] * 4, labels=gl)
+    # (K1 itself on a MOD4 grid: tests/test_gpu_parity.py, test_c2_full_size_against_the_oracle)
     # no seg overlay bound at all (the emission then records no seg labels)
     p3 = dict(p, showSeg=0)
     ref3 = inr.render_brats_inr(p3, grids, net, s["zmu"], s["zsg"], labels=None, one_pass=True)

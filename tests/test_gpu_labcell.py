@@ -113,9 +113,21 @@ def test_label_cells_at_config_2_and_through_the_shim(env):
     k.dispatch(thread_count=[96, 72, 1], vars=vars_)
     assert len(dev._label_cells) == 1                                 # the cell grid was used (and cached)
     assert np.array_equal(tex.tensor.cpu().numpy(), ref)
+    assert len(dev._mod4) == 1                                        # ... and the four modalities as ONE float4 grid (MOD4)
     bufs[5].copy_from_numpy(np.roll(pred, 5))                         # a rewritten prediction buffer must not meet a stale cell grid
     k.dispatch(thread_count=[96, 72, 1], vars=vars_)
     assert np.array_equal(tex.tensor.cpu().numpy(), oc.brats_main(q, vs, seg, np.roll(pred, 5), None))
+    # two of the four switched off, their slots bound to the viewer's one-element dummies (brats_viewer.py:247-248): the MOD4
+    # grid is rebuilt from the two that remain; then a rewritten modality must not meet a stale grid either
+    dummy = dev.create_buffer(element_count=1, struct_size=4)
+    dummy.copy_from_numpy(np.zeros(1, np.float32))
+    q2 = dict(q, volEnabled=(1, 0, 1, 0))
+    vars2 = dict(vars_, gParams=q2, gIntensity1=dummy, gIntensity3=dummy)
+    k.dispatch(thread_count=[96, 72, 1], vars=vars2)
+    assert np.array_equal(tex.tensor.cpu().numpy(), oc.brats_main(q2, vs, seg, np.roll(pred, 5), None))
+    bufs[2].copy_from_numpy(vs[2][::-1].copy())
+    k.dispatch(thread_count=[96, 72, 1], vars=vars2)
+    assert np.array_equal(tex.tensor.cpu().numpy(), oc.brats_main(q2, [vs[0], vs[1], vs[2][::-1].copy(), vs[3]], seg, np.roll(pred, 5), None))
 
 
 def test_label_cells_refuse_what_they_cannot_serve(env):

@@ -482,13 +482,31 @@ def test_c2_full_size_against_the_oracle(env):
     lab = synth.synth_labels(n)
     p = synth.brats_scene(n, image, steps, channels=4, show_seg=True, intensity_alpha=0.4)
     ref, aux = oc.brats_main(p, vols, lab, None, None, return_aux=True)
-    for layout, lab_layout in (("quad", "brick"), ("quad", "labcell"), ("linear", "linear")):
-        g = [mrirt.upload_grid(v, (n, n, n), layout) for v in vols]
+    for layout, lab_layout in (("quad", "brick"), ("quad", "labcell"), ("linear", "linear"), ("mod4", "brick"), ("mod4", "labcell")):
+        # ("mod4": the four modalities as ONE float4 grid, MRIRT_LAYOUT_MOD4 — a quarter of the four quad grids' memory)
+        g = [mrirt.upload_mod4(vols, (n, n, n))] * 4 if layout == "mod4" else [mrirt.upload_grid(v, (n, n, n), layout) for v in vols]
         # ("labcell": the seg overlay as label cells — what bench.py's k1_reference_path and the shim bind on QUAD grids)
         gl = mrirt.upload_label_cells(lab, None, (n, n, n)) if lab_layout == "labcell" else mrirt.upload_grid(lab, (n, n, n), lab_layout)
         got, st = mrirt.render_brats(p, g, gl, ext=dict(layout=layout, labelLayout=lab_layout), stats=True, skip=layout == "quad" and lab_layout == "brick")
         assert np.array_equal(got.cpu().numpy(), ref), layout
         assert st["live_samples"] == aux["live_samples"]
+        if layout == "mod4" and lab_layout == "brick":
+            # which modalities are enabled is a run-time property of the one MOD4 kernel: every subset against four quad grids
+            gq = [mrirt.upload_grid(v, (n, n, n), "quad") for v in vols]
+            for en in ((1, 0, 0, 0), (0, 1, 1, 0), (0, 0, 0, 1), (1, 1, 0, 1), (0, 0, 0, 0)):
+                pe = dict(p, volEnabled=en, imageSize=(160, 128))
+                a4 = mrirt.render_brats(pe, g, gl, ext=dict(layout="mod4", labelLayout="brick"))
+                aq = mrirt.render_brats(pe, gq, gl, ext=dict(layout="quad", labelLayout="brick"))
+                assert torch.equal(a4, aq), en
+            pf = dict(p, gamma=1.7, imageSize=(160, 128))            # the general-gamma and the FAST kernels
+            assert torch.equal(mrirt.render_brats(pf, g, gl, ext=dict(layout="mod4", labelLayout="brick")),
+                               mrirt.render_brats(pf, gq, gl, ext=dict(layout="quad", labelLayout="brick")))
+            fa = mrirt.render_brats(pf, g, gl, ext=dict(layout="mod4", labelLayout="brick", math="fast"))
+            fq = mrirt.render_brats(pf, gq, gl, ext=dict(layout="quad", labelLayout="brick", math="fast"))
+            assert float((fa - fq).abs().max()) < 1e-5
+            with pytest.raises(RuntimeError):                        # no gradients in it
+                mrirt.render_brats(pe, g, gl, ext=dict(synth.SHADE_EXT, layout="mod4", labelLayout="brick"))
+            del gq
         del g, gl
 
 

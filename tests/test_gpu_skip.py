@@ -38,7 +38,7 @@ def mask_fraction(dims):
     return float(bits.mean())
 
 
-@pytest.mark.parametrize("layout,shade,channels", [("vg", True, 1), ("vg", False, 1), ("quad", False, 1), ("quad", False, 3)])
+@pytest.mark.parametrize("layout,shade,channels", [("vg", True, 1), ("vg", False, 1), ("quad", False, 1), ("quad", False, 3), ("mod4", False, 3)])
 @pytest.mark.parametrize("math", ["strict", "fast"])
 def test_skip_is_bit_identical(layout, shade, channels, math):
     import torch
@@ -50,7 +50,10 @@ def test_skip_is_bit_identical(layout, shade, channels, math):
     p["wl"], p["ww"] = np.float32(0.45), np.float32(0.7)            # window floor 0.1 > the air's 0
     ext = dict(synth.SHADE_EXT) if shade else {}
     ext.update(layout=layout, math=math)
-    grids = [mrirt.upload_grid(v, (n, n, n), layout) for v in vols]
+    if layout == "mod4":        # the (three enabled) modalities as one float4 grid; the fourth is one the frame never enables
+        grids = [mrirt.upload_mod4(list(vols) + [None] * (4 - len(vols)), (n, n, n))] * 4
+    else:
+        grids = [mrirt.upload_grid(v, (n, n, n), layout) for v in vols]
     labels = mrirt.upload_grid(lab, (n, n, n), "linear")
     for show_seg in (0, 1):
         p["showSeg"] = np.uint32(show_seg)
