@@ -320,39 +320,51 @@ def pipelined_frames(dev, params, grid, ext, live, frames=40, streams=3):
 def k1_reference_path(dev, frames=20):
     """BASELINE config 2 — the reference's own semantics, its primary parity target (inr/viewer/brats_rt.slang:117-165 as
     the viewer runs it): 256^3 x 4 modalities + seg overlay, 512 x 512 px, 256 steps/ray, perspective, no shading, STRICT
-    math, QUAD voxels (what the shim picks for unshaded frames).  HIP events around `frames` launches on the launch stream."""
+    math.  The four modalities are ONE float4 grid (MRIRT_LAYOUT_MOD4: what the shim binds for unshaded multi-modality frames)
+    and the overlay a label-cell grid; the same frame from four QUAD grids is timed beside it.  HIP events around `frames`
+    launches on the launch stream."""
     import torch
     import mrirt
     from mrirt import synth
     n, image, steps = 256, 512, 256
     vols = [synth.synth_volume(n, 1234 + m, phase=0.3 * m) for m in range(4)]
-    gv = [mrirt.upload_grid(v, (n, n, n), "quad") for v in vols]
     gl = mrirt.upload_label_cells(synth.synth_labels(n), None, (n, n, n))      # the seg overlay as label cells: one 8-byte gather at the cell's own offset (what the shim binds)
     p = synth.brats_scene(n, image, steps, channels=4, show_seg=True, intensity_alpha=0.4)
     out = torch.empty((image, image, 4), dtype=torch.float32, device=dev)
-    ext = dict(layout="quad", math="strict")
-    _, st = mrirt.render_brats(p, gv, labels=gl, out=out, ext=ext, stats=True)
-    for _ in range(3):
-        mrirt.render_brats(p, gv, labels=gl, out=out, ext=ext)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(frames)]
-    for e0, e1 in ev:
-        e0.record(); mrirt.render_brats(p, gv, labels=gl, out=out, ext=ext); e1.record()
-    torch.cuda.synchronize()
-    ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))
-    live = st["live_samples"]
+
+    def timed(gv, layout):
+        ext = dict(layout=layout, math="strict")
+        _, st = mrirt.render_brats(p, gv, labels=gl, out=out, ext=ext, stats=True)
+        for _ in range(3):
+            mrirt.render_brats(p, gv, labels=gl, out=out, ext=ext)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(frames)]
+        for e0, e1 in ev:
+            e0.record(); mrirt.render_brats(p, gv, labels=gl, out=out, ext=ext); e1.record()
+        torch.cuda.synchronize()
+        return float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev])), st["live_samples"], out.clone()
+
+    gq = [mrirt.upload_grid(v, (n, n, n), "quad") for v in vols]
+    ms_quad, _, img_quad = timed(gq, "quad")
+    del gq
+    g4 = mrirt.upload_mod4(vols, (n, n, n))
+    ms, live, img = timed([g4] * 4, "mod4")
+    same = bool(torch.equal(img, img_quad))
     alg = live * (4 * BYTES_PER_SAMPLE + 4) + image * image * BYTES_PER_PIXEL      # 8 taps x 4 B x 4 modalities + one label word
-    compulsory = sum(g.nbytes for g in gv) + gl.nbytes + image * image * BYTES_PER_PIXEL
-    traffic, on_chip, note = measured_traffic(f"C2:{n}:{image}:{steps}:quad:strict:4ch+seg")
+    compulsory = g4.nbytes + gl.nbytes + image * image * BYTES_PER_PIXEL
+    traffic, on_chip, note = measured_traffic(f"C2:{n}:{image}:{steps}:mod4:strict:4ch+seg")
     hbm = traffic if traffic is not None else compulsory
     return {"workload": f"C2: {n}^3 x 4 modalities + seg overlay, {image}x{image} px, {steps} steps/ray, perspective, no shading (the "
-                        "reference's brats_main as the viewer runs it); QUAD voxels + label cells, STRICT math, bit-identical to the oracle",
+                        "reference's brats_main as the viewer runs it); the four modalities as one float4 MOD4 grid + label cells, "
+                        "STRICT math, bit-identical to the oracle",
             "value": round(live / (ms * 1e-3) / 1e6, 1), "unit": "Msamples/s", "ms_per_frame": round(ms, 4), "dtype": "f32",
             "live_samples_per_frame": live, "nominal_samples_per_frame": image * image * steps,
+            "four_quad_grids": {"ms_per_frame": round(ms_quad, 4), "same_bits": same,
+                                "note": "the same frame from one QUAD grid per modality (1.07 GB of voxels instead of 268 MB): round 3's binding"},
             "roofline": {"bound": "hbm", "achieved": round(hbm / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(hbm / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "basis": ("rocprofv3 PMC HBM bytes per launch, " + str(note)) if traffic is not None
-                                  else ("compulsory bytes (the five grids once + framebuffer): a floor; " + str(note)),
-                         "on_chip": on_chip, "kernel": "brats_march_pipe_kernel<strict, QUAD, 4 modalities, labels>",
+                                  else ("compulsory bytes (the two grids once + framebuffer): a floor; " + str(note)),
+                         "on_chip": on_chip, "kernel": "brats_march_pipe_kernel<strict, MOD4, label cells>",
                          "algorithmic_GBs": round(alg / (ms * 1e-3) / 1e9, 1), "algorithmic_bytes_per_launch": alg,
                          "compulsory_bytes_per_launch": compulsory}}
 

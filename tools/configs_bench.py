@@ -34,9 +34,10 @@ vols = [synth.synth_volume(n, 1234 + m, phase=0.3 * m) for m in range(4)]
 lab = synth.synth_labels(n)
 p2 = synth.brats_scene(n, 512, 256, channels=4, show_seg=True, intensity_alpha=0.4)
 t = time.perf_counter(); ref2, aux2 = oracle_c.brats_main(p2, vols, lab, None, return_aux=True); dt2 = time.perf_counter() - t
-for layout in ("linear", "brick", "quad", "quad+cells"):
-    cells = layout == "quad+cells"                  # the seg overlay as label cells (what the shim binds on QUAD frames)
-    gv = [mrirt.upload_grid(v, (n, n, n), "quad" if cells else layout) for v in vols]
+for layout in ("linear", "brick", "quad", "quad+cells", "mod4", "mod4+cells"):
+    cells = layout.endswith("+cells")               # the seg overlay as label cells (what the shim binds on QUAD / MOD4 frames)
+    base = layout.split("+")[0]
+    gv = [mrirt.upload_mod4(vols, (n, n, n))] * 4 if base == "mod4" else [mrirt.upload_grid(v, (n, n, n), base) for v in vols]
     gl = mrirt.upload_label_cells(lab, None, (n, n, n)) if cells else mrirt.upload_grid(lab, (n, n, n), "linear" if layout == "linear" else "brick")
     for math_ in ("strict", "fast"):
         e = dict(math=math_)
@@ -67,7 +68,7 @@ net = inr.pack_mlp(mlp, inr.KIND_FOURIER_RELU, K, 4)
 zmu = [float(v[v != 0].mean()) for v in vols]
 zsg = [float(v[v != 0].std() + 1e-6) for v in vols]
 p5 = synth.brats_scene(n, 512, 256, channels=4, show_seg=True, show_pred=True, intensity_alpha=0.4)
-gv = [mrirt.upload_grid(v, (n, n, n), "quad") for v in vols]
+gv = mrirt.upload_mod4(vols, (n, n, n))
 gl = mrirt.upload_grid(lab, (n, n, n), "brick")
 img, aux = inr.render_brats_inr(p5, gv, net, zmu, zsg, labels=gl, return_aux=True)
 ms5 = timeit(lambda: inr.render_brats_inr(p5, gv, net, zmu, zsg, labels=gl), rounds=5)

@@ -8,7 +8,8 @@ O=$REPO/gpurun_out/r04
 rm -rf $O; mkdir -p $O
 cd $REPO
 bash tools/profile_r04.sh c3_vga "C3:512:1024:512:vga:strict:shade" "pipe_kernel<true, 4" bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-inr --no-k1 --no-scaling-model --no-pipelined > $O/profile_c3.log 2>&1; echo "c3 pmc done"
-bash tools/profile_r04.sh c2_quad "C2:256:512:256:quad:strict:4ch+seg" "pipe_kernel<true, 3, false, 4" tools/c2_run.py 10 > $O/profile_c2.log 2>&1; echo "c2 pmc done"
+bash tools/profile_r04.sh c2_mod4 "C2:256:512:256:mod4:strict:4ch+seg" "pipe_kernel<true, 6, false, 4" tools/c2_run.py 10 0 mod4 > $O/profile_c2.log 2>&1; echo "c2 (mod4) pmc done"
+bash tools/profile_r04.sh c2_quad "C2:256:512:256:quad:strict:4ch+seg" "pipe_kernel<true, 3, false, 4" tools/c2_run.py 10 0 quad > $O/profile_c2q.log 2>&1; echo "c2 (quad) pmc done"
 # the C3 kernel on a 256^3 volume (1.5 GiB of VGA voxels: Infinity-Cache resident), at the same ray spacing in voxels
 # (512^2 px, 256 steps) and at the full image (1024^2 px, 512 steps)
 bash tools/profile_r04.sh c3_256_512px "C3:256:512:256:vga:strict:shade" "pipe_kernel<true, 4" bench.py --volume 256 --image 512 --march-steps 256 --steps 10 --warmup 2 --no-cpu-baseline --no-inr --no-k1 --no-scaling-model --no-pipelined > $O/profile_c3_256a.log 2>&1; echo "c3 256 (512px) pmc done"
@@ -18,7 +19,7 @@ import json, glob, os
 root = os.environ.get("GRAFT_REPO_ROOT", os.getcwd())
 db_path = os.path.join(root, "profiles", "traffic.json")
 db = json.load(open(db_path))
-for tag in ("c3_vga", "c2_quad", "c3_256_512px", "c3_256_1024px"):
+for tag in ("c3_vga", "c2_mod4", "c2_quad", "c3_256_512px", "c3_256_1024px"):
     f = os.path.join(root, "gpurun_out", f"prof_{tag}", "traffic_entry.json")
     if os.path.exists(f):
         for k, v in json.load(open(f)).items():
@@ -42,4 +43,6 @@ python3 bench.py --force-exchange --image 2048 --steps 10 --warmup 2 --no-inr --
 python3 tools/configs_bench.py > $O/configs_bench.txt 2>/dev/null; echo "configs done"
 python3 tools/c5_bench.py > $O/c5_bench.txt 2>/dev/null
 python3 tools/viewer_frame_bench.py > $O/viewer_frame_bench.txt 2>/dev/null
+python3 tools/refine_bench.py > $O/refine_bench.txt 2>/dev/null
+bash tools/profile_c5.sh r04 --chunks 96 > $O/c5_frame_kernel_stats.txt 2>&1
 echo "all done"
