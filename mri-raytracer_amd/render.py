@@ -316,7 +316,7 @@ def kernel_family(params: Mapping[str, Any], ext: Optional[Mapping[str, Any]] = 
     P = brats_params(params)
     E = render_ext(dict(ext or {}))
     fake = C.c_void_p(0x1000)
-    vp = (C.c_void_p * 4)(*[fake if P.volEnabled[m] != 0 else None for m in range(4)])
+    vp = (C.c_void_p * 4)(*[fake if (P.volEnabled[m] != 0 or int(E.layout) == _lib.LAYOUT_MOD4) else None for m in range(4)])
     S = None
     if skip:
         S = _lib.Skip()

@@ -317,6 +317,10 @@ def test_kernel_family_choices_incl_the_4gib_fallbacks():
     assert fam(c2, dict(layout="quad", labelLayout="labcell")) == {"family": "pipelined", "skipping": False, "label_cells": True}
     assert fam(c2, dict(layout="quad", labelLayout="brick"), skip=True) == {"family": "pipelined", "skipping": True, "label_cells": False}
     assert fam(c2, dict(layout="linear"))["family"] == "pipelined"                 # the plain ABI's own buffers
+    # the four modalities as one float4 grid (MOD4): the pipelined march, with label cells, with skipping — whatever is enabled
+    assert fam(c2, dict(layout="mod4", labelLayout="labcell")) == {"family": "pipelined", "skipping": False, "label_cells": True}
+    assert fam(c2, dict(layout="mod4", labelLayout="brick"), skip=True) == {"family": "pipelined", "skipping": True, "label_cells": False}
+    assert fam(dict(c2, volEnabled=(0, 0, 0, 0)), dict(layout="mod4"))["family"] == "pipelined"
     four = synth.brats_scene(256, 512, 256, channels=4)
     assert fam(four, dict(synth.SHADE_EXT, layout="vga"))["family"] == "rolling"
     assert fam(dict(four, showSeg=1), dict(synth.SHADE_EXT, layout="vga"))["family"] == "generic"      # overlays: the generic kernel measured faster
@@ -333,6 +337,11 @@ def test_kernel_family_choices_incl_the_4gib_fallbacks():
     import pytest as _pt
     with _pt.raises(_lib_error()):
         fam(synth.brats_scene(0, 64, 64, dims=(1024, 1024, 272), channels=1), dict(synth.SHADE_EXT, layout="vga"))
+    # MOD4 has the pipelined kernels only: shading, and grids from 4 GiB upwards, are refused (MRIRT_ERR_LAYOUT)
+    with _pt.raises(_lib_error()):
+        fam(c2, dict(synth.SHADE_EXT, layout="mod4"))
+    with _pt.raises(_lib_error()):
+        fam(synth.brats_scene(0, 64, 64, dims=(1024, 1024, 272), channels=4), dict(layout="mod4"))
 
 
 def _lib_error():
