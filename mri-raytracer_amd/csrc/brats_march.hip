@@ -769,7 +769,7 @@ struct EmitArgs {
     float* mix;                  // C5 passes: the sample's weighted intensity (float per row), or with shading
                                  // (intensity, gradient) as float4 per row; and its seg label when showSeg
     uint32_t* seg;
-    const float4* geom;          // chunked C5: per pixel (ro, rd.x), (rd.y, rd.z, t1, hit) — written once by the plan kernel
+    const float4* geom;          // chunked C5: per pixel (rd, t1), (ro, hit) — written once by the plan kernel
 };
 
 // MLP inputs of the sample at index-space cell `s` -> row `row` of coords / feats (shared by the one-pass and
@@ -798,14 +798,17 @@ __device__ __forceinline__ void emit_row(const K1Args& a, const EmitArgs& e, con
         const float v = sv[m];
         z[m] = STRICT ? Mm::divu_data(v - e.zmu[m], e.zsigma[m]) : (v - e.zmu[m]) * e.zsigma[m].r;
     }
+    struct __attribute__((packed, aligned(4))) Coord3 { float x, y, z; };      // one 12-byte store (global memory takes it 4-byte aligned)
+    float c3[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {    // fp64, one rounding: predict_volume's coordinate at lattice points
         // x / (dim - 1) exactly (Markstein: dim - 1 is a small integer, its significand is never all ones)
         const double x = (double)clampf(s.q[k], 0.0f, a.hiLab[k]);
         const double q0 = x * e.rdimM1[k];
         const double q = __builtin_fma(__builtin_fma(-q0, e.dimM1[k], x), e.rdimM1[k], q0);
-        e.coords[row * 3 + k] = (float)(q * 2.0 - 1.0);
+        c3[k] = (float)(q * 2.0 - 1.0);
     }
+    reinterpret_cast<Coord3*>(e.coords)[row] = Coord3{ c3[0], c3[1], c3[2] };
     e.feats[row] = make_float4(z[0], z[1], z[2], z[3]);
 }
 
@@ -907,8 +910,8 @@ __global__ __launch_bounds__(256) void c5_plan_kernel(const K1Args a, C5Ray* __r
         const bool hit = setup_ray(a, px, py, ro, rd, t0, t1);
         goes = hit && r.T > a.ert;
         r.t = t0;
-        geom[2 * pix] = make_float4(ro[0], ro[1], ro[2], rd[0]);
-        geom[2 * pix + 1] = make_float4(rd[1], rd[2], t1, hit ? 1.0f : 0.0f);
+        geom[2 * pix] = make_float4(rd[0], rd[1], rd[2], t1);                     // what every reader needs
+        geom[2 * pix + 1] = make_float4(ro[0], ro[1], ro[2], hit ? 1.0f : 0.0f);  // (perspective: the origin is the eye — read only under an orthographic camera)
     }
     c5_plan_rows(a, mine, pix, r, goes, t1, rays, rowOwner, counter, chunk);
 }
@@ -935,8 +938,10 @@ __global__ __launch_bounds__(256) void c5_emit_kernel(const K1Args a, const Emit
         const uint32_t row = ((g0 + j) << 8) + threadIdx.x;
         if (row >= n) break;
         const uint2 own = rowOwner[row];
-        const float4 ga = e.geom[2 * (size_t)own.x], gb = e.geom[2 * (size_t)own.x + 1];
-        const float ro[3] = { ga.x, ga.y, ga.z }, rd[3] = { ga.w, gb.x, gb.y };
+        const float4 ga = e.geom[2 * (size_t)own.x];
+        float ro[3] = { a.cam.eye[0], a.cam.eye[1], a.cam.eye[2] };               // perspective: primary_ray's origin
+        if (a.cam.mode != 0) { const float4 gb = e.geom[2 * (size_t)own.x + 1]; ro[0] = gb.x; ro[1] = gb.y; ro[2] = gb.z; }   // uniform
+        const float rd[3] = { ga.x, ga.y, ga.z };
         const float t = __uint_as_float(own.y);
         Cell s;
         locate<STRICT>(a, ro, rd, t, s);
@@ -959,9 +964,13 @@ __global__ __launch_bounds__(256) void c5_emit_kernel(const K1Args a, const Emit
                 v = Mm::mad(sv[m], a.weight[m], v);
             }
         }
-        if constexpr (SHADE) reinterpret_cast<float4*>(e.mix)[row] = make_float4(v, g[0], g[1], g[2]);
-        else e.mix[row] = v;
-        if (a.showSeg != 0) e.seg[row] = sample_label(a.labels, a.lab, s.q, a.hiLab);
+        if constexpr (SHADE) {
+            reinterpret_cast<float4*>(e.mix)[row] = make_float4(v, g[0], g[1], g[2]);
+            if (a.showSeg != 0) e.seg[row] = sample_label(a.labels, a.lab, s.q, a.hiLab);
+        } else {                     // unshaded: (weighted intensity, seg label) as ONE 8-byte record in the mix array
+            const uint32_t l = a.showSeg != 0 ? sample_label(a.labels, a.lab, s.q, a.hiLab) : 0u;
+            reinterpret_cast<uint2*>(e.mix)[row] = make_uint2(__float_as_uint(v), l);
+        }
     }
 }
 
@@ -988,8 +997,9 @@ __global__ __launch_bounds__(256) void c5_composite_kernel(const K1Args a, C5Ray
         st = rays[pix];
         r.C0 = st.C0; r.C1 = st.C1; r.C2 = st.C2; r.T = st.T;
         if (nextCounter != nullptr || (SHADE && st.cnt != 0)) {
-            const float4 g0 = geom[2 * pix], g1 = geom[2 * pix + 1];
-            rd[0] = g0.w; rd[1] = g1.x; rd[2] = g1.y; t1 = g1.z; hit = g1.w != 0.0f;
+            const float4 g0 = geom[2 * pix];
+            rd[0] = g0.x; rd[1] = g0.y; rd[2] = g0.z; t1 = g0.w;
+            hit = geom[2 * pix + 1].w != 0.0f;
         }
     }
     struct Rec { float v, g[3]; Labels lb; };
@@ -999,10 +1009,12 @@ __global__ __launch_bounds__(256) void c5_composite_kernel(const K1Args a, C5Ray
             if constexpr (SHADE) {
                 const float4 m = reinterpret_cast<const float4*>(mix)[row];
                 c.v = m.x; c.g[0] = m.y; c.g[1] = m.z; c.g[2] = m.w;
+                if (a.showSeg != 0) c.lb.seg = seg[row];
             } else {
-                c.v = mix[row];
+                const uint2 m = reinterpret_cast<const uint2*>(mix)[row];
+                c.v = __uint_as_float(m.x);
+                c.lb.seg = m.y;                  // (0 when the overlay is off: the emission wrote it so)
             }
-            if (a.showSeg != 0) c.lb.seg = seg[row];
             c.lb.pred = (uint32_t)(uint16_t)classes[row];
         }
     };
