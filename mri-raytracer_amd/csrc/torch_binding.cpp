@@ -85,11 +85,13 @@ Tensor render_brats(const Tensor& params, const Tensor& ext, const OptTensor& vo
     const void* vp[4];
     const int64_t need = grid_need(P.dims, E.layout), lneed = grid_need(P.dims, E.labelLayout);
     std::optional<at::Device> dev;
+    const bool mod4 = E.layout == MRIRT_LAYOUT_MOD4;                    // vol0 = the float4 grid of all four modalities
     for (int m = 0; m < 4; ++m) {
         vp[m] = dev_ptr(*vols[m], at::kFloat, names[m]);
         same_device(dev, *vols[m], names[m]);
-        TORCH_CHECK_VALUE(P.volEnabled[m] == 0 || (vols[m]->has_value() && (*vols[m])->numel() >= need),
-                          names[m], " is enabled but holds fewer than ", need, " elements");
+        const bool wanted = mod4 ? m == 0 : P.volEnabled[m] != 0;
+        TORCH_CHECK_VALUE(!wanted || (vols[m]->has_value() && (*vols[m])->numel() >= need),
+                          names[m], mod4 ? " (the MOD4 grid) holds fewer than " : " is enabled but holds fewer than ", need, " elements");
     }
     TORCH_CHECK_VALUE(dev.has_value(), "no intensity grid bound");
     const void* lab = dev_ptr(labels, at::kInt, "gLabels");

@@ -137,9 +137,10 @@ def render_brats(params: torch.Tensor, ext: torch.Tensor, vol0: Optional[torch.T
     lab = _dev_flat(labels, torch.int32, "gLabels")
     prd = _dev_flat(preds, torch.int32, "gPreds")
     need, lneed = _grid_need(dims, E.layout), _grid_need(dims, E.labelLayout)
+    mod4 = E.layout == _lib.LAYOUT_MOD4                  # vol0 = the float4 grid of all four modalities (vol1..3 are ignored)
     for m, v in enumerate(vols):
-        if P.volEnabled[m] != 0 and (v is None or v.numel() < need):
-            raise ValueError(f"gIntensity{m} is enabled but holds {0 if v is None else v.numel()} < {need} elements")
+        if (m == 0 if mod4 else P.volEnabled[m] != 0) and (v is None or v.numel() < need):
+            raise ValueError(f"gIntensity{m} is {'the MOD4 grid' if mod4 else 'enabled'} but holds {0 if v is None else v.numel()} < {need} elements")
     if P.showSeg != 0 and (lab is None or lab.numel() < lneed):
         raise ValueError("showSeg is set but gLabels is missing or too small")
     cells = E.labelLayout == _lib.LAYOUT_LABCELL     # gLabels carries both grids, gPreds is ignored

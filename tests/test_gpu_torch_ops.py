@@ -39,6 +39,18 @@ def test_render_brats_op_equals_api_and_oracle():
                                                             gq.data, None, None, None, cells.data, None), opq)      # the C++ extension
     with pytest.raises(ValueError):
         torch.ops.mrirt.render_brats(torch_ops.pack_brats_params(q), torch_ops.pack_render_ext(extq), gq.data, None, None, None, cells.data[:64], None)
+    # four modalities as ONE float4 grid (MOD4), bound as gIntensity0 alone; label cells; both operator libraries
+    vols4 = [synth.synth_volume(n, 1234 + m, phase=0.3 * m) for m in range(4)]
+    q4 = synth.brats_scene(n, image, 64, channels=4, show_seg=True, show_pred=True, intensity_alpha=4.0)
+    ref4 = oracle_c.brats_main(q4, vols4, lab, pred, None)
+    g4 = mrirt.upload_mod4(vols4, (n, n, n))
+    ext4 = dict(layout="mod4", labelLayout="labcell")
+    op4 = torch.ops.mrirt.render_brats(torch_ops.pack_brats_params(q4), torch_ops.pack_render_ext(ext4), g4.data, None, None, None, cells.data, None)
+    assert np.array_equal(op4.cpu().numpy(), ref4)
+    assert torch.equal(torch_ops.load_native().render_brats(torch_ops.pack_brats_params(q4), torch_ops.pack_render_ext(ext4),
+                                                            g4.data, None, None, None, cells.data, None), op4)
+    with pytest.raises(ValueError):
+        torch.ops.mrirt.render_brats(torch_ops.pack_brats_params(q4), torch_ops.pack_render_ext(ext4), g4.data[:1000], None, None, None, cells.data, None)
     # the size checks the C ABI cannot make
     with pytest.raises(ValueError):
         torch.ops.mrirt.render_brats(torch_ops.pack_brats_params(p), torch_ops.pack_render_ext(ext),
