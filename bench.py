@@ -700,7 +700,9 @@ def main():
                          "traffic": traffic,
                          "basis": (("rocprofv3 PMC HBM bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE), " + str(note)) if traffic is not None
                                    else ("compulsory bytes (volume once + framebuffer): a floor of the real traffic; " + str(note)))
-                                  + "; HBM is not what limits this kernel: see on_chip.td_return_frac (the texture data-return path) and l1_hit_rate",
+                                  + "; the HBM PEAK is not what limits this kernel — two roofs 12 % apart do: the texture data-return path (on_chip.td_return_frac, "
+                                    "l1_hit_rate; reached on an Infinity-Cache-resident volume) and, on this volume, the latency of the lines that come from beyond L2 "
+                                    "(the FAST-math build keeps the full 2.39 GHz where STRICT is power-throttled to 2.26 and takes the same time: profiles/r04_power_clocks/)",
                          # what actually binds the kernel (PMC passes): its gathers are served by L1/L2
                          "on_chip": on_chip,
                          "kernel": "brats_march_pipe_kernel" if not a.variant & 4 else "brats_march_kernel", "kernel_ms": round(kernel_ms, 4),
