@@ -510,6 +510,36 @@ def test_c2_full_size_against_the_oracle(env):
         del g, gl
 
 
+def test_mod4_odd_dims_cameras_and_overlays_against_the_oracle(env):
+    """The MOD4 grid on volumes whose sides are odd (the 2 x 2 x 2 bricks are padded), from cameras outside and inside the box, with
+    weights that are not 1, both overlays as plain label grids and as label cells, and exact empty-space skipping: whole frames
+    and live-sample counts against the oracle."""
+    torch, mrirt, synth, oc = env["torch"], env["mrirt"], env["synth"], env["oc"]
+    rng = np.random.default_rng(5)
+    for dims, hw in (((37, 29, 23), (57, 75)), ((19, 44, 31), (64, 40))):
+        vols = [synth.synth_volume(0, 77 + m, phase=0.2 * m, dims=dims) for m in range(4)]
+        lab = synth.synth_labels(0, dims=dims)
+        prd = np.roll(lab, 11).copy()
+        g4 = mrirt.upload_mod4(vols, dims)
+        plain = (mrirt.upload_grid(lab, dims, "brick"), mrirt.upload_grid(prd, dims, "brick"))
+        cells = mrirt.upload_label_cells(lab, prd, dims)
+        for case in range(4):
+            p = synth.brats_scene(0, 0, 90, dims=dims, image_hw=hw, channels=4, show_seg=True, show_pred=bool(case & 1), intensity_alpha=3.0)
+            p["volWeight"] = tuple(np.float32(v) for v in (1.0, 0.5, 2.0, 0.25))
+            p["volEnabled"] = ((1, 1, 1, 1), (1, 0, 1, 1), (0, 1, 0, 0), (1, 1, 0, 1))[case]
+            cam = mrirt.OrbitalCamera(initial_radius=(2.4, 0.35, 1.6, 3.0)[case], initial_phi=float(rng.uniform(0, 6.28)),
+                                      initial_theta=float(rng.uniform(-1.2, 1.2)))
+            p["eye"], p["U"], p["V"], p["W"] = cam.get_basis()
+            ref, aux = oc.brats_main(p, vols, lab, prd if case & 1 else None, None, return_aux=True)
+            a, sa = mrirt.render_brats(p, [g4] * 4, plain[0], plain[1] if case & 1 else None, stats=True)
+            assert np.array_equal(a.cpu().numpy(), ref), (dims, case)
+            assert sa["live_samples"] == aux["live_samples"]
+            b = mrirt.render_brats(p, [g4] * 4, cells)
+            assert torch.equal(a, b), (dims, case, "label cells")
+            c, sc = mrirt.render_brats(p, [g4] * 4, plain[0], plain[1] if case & 1 else None, stats=True, skip=True)
+            assert torch.equal(a, c) and sc == sa, (dims, case, "skip")
+
+
 def test_frames_in_flight_on_slot_streams(env):
     """The N > 1 frame loop of bench.py: DEPTH frames in flight, slot s of FrameExchange on its own HIP stream (wait for the slot's
     previous exchange -> march into the slot's compact buffer -> submit).  Single process (the exchange is a device copy), three
