@@ -196,6 +196,14 @@ def test_c5_chunked_is_bit_identical_to_one_pass(setup, kind):
     with pytest.raises(RuntimeError):                    # no gradients in it: MRIRT_ERR_LAYOUT
         inr.render_brats_inr(p, m4, net, s["zmu"], s["zsg"], labels=gl, ext=dict(synth.SHADE_EXT, layout="mod4"))
     # (K1 itself on a MOD4 grid: tests/test_gpu_parity.py, test_c2_full_size_against_the_oracle)
+    # an orthographic camera: every ray has its own ORIGIN (the emission then reads it from the per-ray record the plan kernel
+    # wrote; under a perspective camera it is the eye) — chunked passes on both bindings against the whole-ray form
+    eo = dict(cameraMode=1, orthoHalfHeight=0.8)
+    ref_o = inr.render_brats_inr(p, grids, net, s["zmu"], s["zsg"], labels=gl, ext=eo, one_pass=True)
+    assert not torch.equal(ref_o, ref)
+    for g in (grids, m4):
+        for chunk in (7, 32):
+            assert torch.equal(inr.render_brats_inr(p, g, net, s["zmu"], s["zsg"], labels=gl, ext=eo, chunk_steps=chunk), ref_o), chunk
     # no seg overlay bound at all (the emission then records no seg labels)
     p3 = dict(p, showSeg=0)
     ref3 = inr.render_brats_inr(p3, grids, net, s["zmu"], s["zsg"], labels=None, one_pass=True)
