@@ -164,8 +164,11 @@ class ComputeKernel:
         if hit is None:
             n = dims[0] * dims[1] * dims[2]
             g = _r.upload_mod4([b.tensor[:n] if b is not None else None for b in bufs], dims)
-            cache.clear()                                   # one case at a time; the entry keeps its buffers alive
+            while len(cache) >= 3:                          # a few enabled-sets of one case (the viewer's check boxes toggle between
+                cache.pop(next(iter(cache)))                # them); an entry keeps its buffers alive
             hit = cache[key] = (g, tuple(bufs))
+        else:
+            cache[key] = cache.pop(key)                     # most recently used last
         return hit[0]
 
     def _buf(self, b, dims, layout):
