@@ -26,7 +26,7 @@ extern "C" {
 
 /* 3: MRIRT_LAYOUT_LABCELL + mrirt_build_label_cells, MrirtInrDesc.flags / tieSigmas (they replace the process-environment
  *    switches of version 2), mrirt_brats_skip_applicable, mrirt_install_abort_trace. */
-/* 4: MRIRT_LAYOUT_MOD4 + mrirt_build_mod4_grid (the four modalities of a BraTS case as ONE float4 grid, read by
+/* 4: MRIRT_LAYOUT_MOD4 + mrirt_build_mod4_grid (the four modalities of a BraTS case as ONE float4 grid: unshaded K1 and
  *    mrirt_render_brats_inr); the packed INR image ends in 32 KiB of slack more (mrirt_inr_pack_bytes says how much to allocate). */
 #define MRIRT_ABI_VERSION 4
 
@@ -94,12 +94,15 @@ typedef enum MrirtLayout {
      * gathers.  mrirt_build_label_cells makes it; `labels` points at it, `preds` is ignored.                              */
     MRIRT_LAYOUT_LABCELL = 5,
     /* MOD4 = the FOUR modalities of one case interleaved: float4 (gIntensity0..3)[voxel] in the VG grid's element order
-     *        (2x2x2-voxel bricks of 8 x 16 B, mrirt_vec4_elems).  The per-sample network of mrirt_render_brats_inr reads all
-     *        four at every sample: eight 16-byte gathers bring the eight corners of ALL of them (the same 128 B per sample as
-     *        four QUAD grids) from a grid a quarter of the size — 268 MB instead of 1.07 GB for 256^3 x 4, one set of cache
-     *        lines per sample instead of four.  Trilinear arithmetic unchanged (sampleLinear's order): same bits.
-     *        mrirt_build_mod4_grid makes it; vol[0] points at it (vol[1..3] are ignored).  mrirt_render_brats_inr only
-     *        (unshaded); every other entry point returns MRIRT_ERR_LAYOUT for it.                                        */
+     *        (2x2x2-voxel bricks of 8 x 16 B, mrirt_vec4_elems).  An unshaded sample of a multi-modality frame — the reference
+     *        viewer's own frame, and the per-sample network of mrirt_render_brats_inr — takes eight 16-byte gathers for the eight
+     *        corners of ALL four modalities (the same 128 B per sample as four QUAD grids) from a grid a quarter of the size:
+     *        268 MB instead of 1.07 GB for 256^3 x 4, one set of cache lines per sample instead of four.  Trilinear arithmetic
+     *        unchanged (sampleLinear's order): same bits.  mrirt_build_mod4_grid makes it; vol[0] points at it (vol[1..3] are
+     *        ignored); which modalities are drawn stays volEnabled; label grids as before or as MRIRT_LAYOUT_LABCELL.
+     *        mrirt_render_brats_ex / _skip (the pipelined march) and mrirt_render_brats_inr.  MRIRT_ERR_LAYOUT with gradient
+     *        shading (no gradients in it), with a class stream (mrirt_render_brats_stream), and for grids of 4 GiB or label
+     *        grids of 2^30 elements upwards.                                                                                 */
     MRIRT_LAYOUT_MOD4 = 6
 } MrirtLayout;
 
@@ -386,7 +389,7 @@ int mrirt_inr_predict_volume(const MrirtInrDesc* desc, const float* mods, const 
  *   net      : Fourier/ReLU (MRIRT_INR_FOURIER_RELU) or SIREN (MRIRT_INR_SIREN, the 7-input network of
  *              notebooks/neumors_inr.ipynb:853-899,1165-1178: x = (coords, 4 z-scored modalities)), numMods == 4
  *   scratch  : device memory of mrirt_brats_inr_scratch_bytes(params, chunk_steps) bytes, owned by the caller
- *              (58 B per pixel per step of a pass + 32 B per pixel: 0.49 GB for 512 x 512 x 32)
+ *              (58 B per pixel per step of a pass + 64 B per pixel + 12 KiB: 1.5 GB for 512 x 512 x 96)
  *   stats_dev: optional, THREE device uint64 counters, atomically incremented by
  *              {composited (live) samples, gradient-shaded samples, MLP queries}
  * The frame is bit-identical to mrirt_brats_sample_counts / _emit_samples / mrirt_render_brats_stream run over whole rays (the MLP is batch-position invariant). */

@@ -931,8 +931,9 @@ __global__ __launch_bounds__(256) void c5_emit_kernel(const K1Args a, const Emit
     using Mm = M<STRICT>;
     const uint32_t n = *counter, nGroups = (n + 255u) >> 8;
     // a workgroup takes kEmitRun consecutive 256-row groups at a time: the rows of a wave's rays follow one another step by
-    // step (C5Rows), so a run is ~kEmitRun * 4 consecutive steps of the same 64 rays and their gathers hit the lines the
-    // previous steps brought into this CU's L1 (a plain grid stride sent every fifth step of a bundle to another CU)
+    // step (C5Rows), so a run is ~kEmitRun * 4 consecutive steps of the same 64 rays on one CU.  (Measured level with a plain
+    // grid stride — runs of 1 / 4 / 8 groups 219 / 214 / 219 us per pass, 24: 232 — the emission is bound by the number of
+    // its vector-memory instructions, not by where their lines are; kept at 8.)
     for (uint32_t g0 = blockIdx.x * kEmitRun; g0 < nGroups; g0 += gridDim.x * kEmitRun)
     for (uint32_t j = 0; j < kEmitRun && g0 + j < nGroups; ++j) {
         const uint32_t row = ((g0 + j) << 8) + threadIdx.x;

@@ -19,7 +19,7 @@ EXT_DEFAULTS: Dict[str, Any] = dict(
     ertThreshold=None,            # None -> the shader's hard-coded 0.01 (brats_rt.slang:117)
     math="strict",                # "strict" (bit-faithful) | "fast"
     outFormat="rgba32f",          # "rgba32f" | "rgba16f" (the reference's texture format)
-    layout="linear",              # intensity grids: "linear" | "brick" | "vg" | "quad" | "vga" | "mod4" (render_brats_inr only)
+    layout="linear",              # intensity grids: "linear" | "brick" | "vg" | "quad" | "vga" | "mod4" (unshaded frames)
     labelLayout="linear",         # labels / preds: "linear" | "brick" | "labcell" (both overlays per cell: upload_label_cells)
     tileSize=0, tileRank=0, tileWorld=0, tileSkew=0,
     kernelVariant=0,
