@@ -1146,12 +1146,13 @@ __global__ __launch_bounds__(256, 1) void inr_ws_kernel(const InrArgs a) {
 // THREE tiles ahead of the MFMAs: a tile's MFMAs take 0.6 us and an L2 round trip more than that, so one tile in
 // flight left the kernel latency-bound (measured: 2.8 us per tile).  The DMAs span the workgroup barriers: counted
 // s_waitcnt vmcnt(2 tiles' pieces) + a raw s_barrier per tile (guide: "Pipelining across barriers"); every tile is
-// exactly PERW DMA instructions per wave (short tiles repeat their last fragment into unused slots) so that the
-// count is one immediate; the stream is cyclic (after the head comes layer 0 again), so a batch starts with its
-// first three tiles already in LDS.
+// exactly PERW DMA instructions per wave (a full ring slot: a short tile drags the fragments behind it into slots nobody
+// reads) so that the count is one immediate, and in the hidden layers they are issued one at a time between the k steps
+// (issue_part); the stream is cyclic (after the head comes layer 0 again), so a batch starts with its first three tiles
+// already in LDS.
 // Work list: a workgroup scans interleaved 2048-point segments of the class array for marks (16-byte loads), collects the point
-// ids in LDS and runs a batch whenever 128 are waiting (the remainder at the end): no global compaction pass, no
-// atomics on global memory, nothing for the host to size.
+// ids in LDS and runs a batch whenever 128 are waiting (the remainder at the end): no global compaction pass, nothing for
+// the host to size; the only global atomic is the optional segment ticket (InrArgs::segTicket: the C5 passes).
 // =====================================================================================================
 constexpr int kRefWaves = 4;
 // Diagnostic build (-DMRIRT_REF_STAMPS): s_memtime at the phase boundaries of every workgroup's second batch goes to the logits
