@@ -278,7 +278,10 @@ def inr_path(dev, frames=5):
                                        "67.1 M resident random queries, 5 launches back to back", "ms_per_launch": round(ms, 3),
                            "Mqueries_s": round(nq / (ms * 1e-3) / 1e6, 1),
                            "roofline": {"bound": "mfma", "achieved": round(tflops, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
-                                        "unit": "TFLOP/s", "frac": round(tflops / MFMA_BF16_PEAK_TFLOPS, 4)},
+                                        "unit": "TFLOP/s", "frac": round(tflops / MFMA_BF16_PEAK_TFLOPS, 4),
+                                        "basis": "2 x sum(in x out) flop per query over the launch time; the peak is the 2.4 GHz figure — under this kernel the "
+                                                 "socket sits at its power limit (1.34-1.37 kW) and holds 1.73-2.15 GHz (in-kernel cycle counts / rocm-smi: "
+                                                 "profiles/r04_power_clocks/), so that closing issue gaps buys lower clocks"},
                            "with_near_tie_refinement": {"ms_per_launch": round(ms_refined, 3), "Mqueries_s": round(nq / (ms_refined * 1e-3) / 1e6, 1),
                                                         "note": "classes as shipped: + inr_refine_kernel (split-bf16, three MFMAs per product) on the "
                                                                 "points whose top-2 logit gap is below 3 sqrt(2) x the calibrated rms error "
