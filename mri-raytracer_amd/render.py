@@ -281,6 +281,8 @@ def _bind_brats(params, intensities, labels, preds, ext, dev, pred_stream: bool 
             "vga": 4 * vga_elems(dims), "labcell": 2 * vec4_elems(dims), "mod4": 4 * vec4_elems(dims)}
     if lab_lay == "labcell" and lay not in ("quad", "mod4"):
         raise ValueError("label cells (upload_label_cells) go with 'quad' or 'mod4' intensity grids")
+    if lay == "mod4" and len(intensities) >= 1:          # ONE grid carries all four modalities: [g], [g] * 4 or (g, None, None, None)
+        intensities = [intensities[0]] * 4
     vols = []
     for m in range(4):
         v = intensities[m] if m < len(intensities) else None
