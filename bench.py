@@ -281,7 +281,8 @@ def inr_path(dev, frames=5):
                                         "unit": "TFLOP/s", "frac": round(tflops / MFMA_BF16_PEAK_TFLOPS, 4),
                                         "basis": "2 x sum(in x out) flop per query over the launch time; the peak is the 2.4 GHz figure — under this kernel the "
                                                  "socket sits at its power limit (1.34-1.37 kW) and holds 1.73-2.15 GHz (in-kernel cycle counts / rocm-smi: "
-                                                 "profiles/r04_power_clocks/), so that closing issue gaps buys lower clocks"},
+                                                 "profiles/r04_power_clocks/); issued back to back on random operands this instruction mix sustains 0.59 of the peak "
+                                                 "(tools/micro/mfma_power.hip), plain MFMA chains 0.685"},
                            "with_near_tie_refinement": {"ms_per_launch": round(ms_refined, 3), "Mqueries_s": round(nq / (ms_refined * 1e-3) / 1e6, 1),
                                                         "note": "classes as shipped: + inr_refine_kernel (split-bf16, three MFMAs per product) on the "
                                                                 "points whose top-2 logit gap is below 3 sqrt(2) x the calibrated rms error "
